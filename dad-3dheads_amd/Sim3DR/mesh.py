@@ -1,0 +1,129 @@
+"""Batched, device-resident Sim3DR: torch CUDA tensors in, torch CUDA tensors out, async on the current stream.
+
+One `Mesh` = one static triangle list (uploaded once together with its vertex->face incidence list).
+All methods take a leading batch dimension; nothing is copied to the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _lib
+
+
+def _chk(t: Tensor, dtype, ndim: int, name: str, dev: torch.device) -> Tensor:
+    if t.dtype != dtype or t.ndim != ndim or not t.is_contiguous() or t.device != dev:
+        raise ValueError(f"{name}: expected a contiguous {dtype} tensor with {ndim} dims on {dev}, "
+                         f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t
+
+
+class Mesh:
+    def __init__(self, triangles, nver: int, device: Optional[int] = None):
+        tri = np.ascontiguousarray(np.asarray(triangles))
+        if tri.dtype != np.int32:
+            raise ValueError(f"Buffer dtype mismatch, expected 'int' but got '{tri.dtype}'")  # rasterize.pyx typed buffer
+        if tri.ndim != 2 or tri.shape[1] != 3:
+            raise ValueError("triangles must have shape [ntri, 3]")
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.ntri, self.nver = int(tri.shape[0]), int(nver)
+        h = C.c_void_p()
+        _lib.check(self._lib.dad3d_mesh_create(tri.ctypes.data, self.ntri, self.nver, self.device_index, C.byref(h)))
+        self._handle = h
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            try:
+                self._lib.dad3d_mesh_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def torch_device(self) -> torch.device:
+        return torch.device("cuda", self.device_index)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.torch_device).cuda_stream
+
+    # -- normals -----------------------------------------------------------------------------------
+    def get_normal(self, vertices: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+        """`_get_normal` per image: vertices [B,nver,3] -> unit vertex normals [B,nver,3]."""
+        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        if out is None:
+            if accumulate:
+                raise ValueError("accumulate=True needs `out`")
+            out = torch.empty_like(v)
+        _chk(out, torch.float32, 3, "out", self.torch_device)
+        _lib.check(self._lib.dad3d_mesh_get_normal(self._handle, out.data_ptr(), v.data_ptr(), v.shape[0],
+                                                   _lib.NORMAL_ACCUMULATE if accumulate else 0, self._stream()))
+        return out
+
+    def get_tri_normal(self, vertices: Tensor, norm_flg: bool = False) -> Tensor:
+        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        out = torch.empty((v.shape[0], self.ntri, 3), dtype=torch.float32, device=v.device)
+        _lib.check(self._lib.dad3d_mesh_get_tri_normal(self._handle, out.data_ptr(), v.data_ptr(), v.shape[0], int(norm_flg), self._stream()))
+        return out
+
+    def get_ver_normal(self, tri_normal: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+        t = _chk(tri_normal, torch.float32, 3, "tri_normal", self.torch_device)
+        if out is None:
+            out = torch.empty((t.shape[0], self.nver, 3), dtype=torch.float32, device=t.device)
+        _lib.check(self._lib.dad3d_mesh_get_ver_normal(self._handle, out.data_ptr(), t.data_ptr(), t.shape[0],
+                                                       _lib.NORMAL_ACCUMULATE if accumulate else 0, self._stream()))
+        return out
+
+    # -- raster ------------------------------------------------------------------------------------
+    def rasterize(self, vertices: Tensor, colors: Tensor, bg: Tensor, depth: Optional[Tensor] = None,
+                  reverse: bool = False, alpha: float = 1.0) -> Tensor:
+        """`_rasterize` per image, in place on `bg` [B,h,w,c] uint8 (returned). colors [B,nver,c] in [0,1]."""
+        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        img = _chk(bg, torch.uint8, 4, "bg", self.torch_device)
+        col = _chk(colors, torch.float32, 3, "colors", self.torch_device)
+        b, h, w, c = img.shape
+        if col.shape != (b, self.nver, c) or v.shape != (b, self.nver, 3):
+            raise ValueError("vertices/colors/bg batch or channel mismatch")
+        dptr = None
+        if depth is not None:
+            dptr = _chk(depth, torch.float32, 3, "depth", self.torch_device).data_ptr()
+        _lib.check(self._lib.dad3d_mesh_rasterize(self._handle, img.data_ptr(), v.data_ptr(), col.data_ptr(), dptr,
+                                                  b, h, w, c, float(alpha), int(reverse), self._stream()))
+        return img
+
+    def rasterize_triangles(self, vertices: Tensor, h: int, w: int, depth: Optional[Tensor] = None):
+        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        b = v.shape[0]
+        if depth is None:
+            depth = torch.full((b, h, w), -1e8, dtype=torch.float32, device=v.device)
+        tri_buf = torch.full((b, h, w), -1, dtype=torch.int32, device=v.device)
+        bary = torch.zeros((b, h, w, 3), dtype=torch.float32, device=v.device)
+        _lib.check(self._lib.dad3d_mesh_rasterize_triangles(self._handle, v.data_ptr(), depth.data_ptr(), tri_buf.data_ptr(),
+                                                            bary.data_ptr(), b, h, w, self._stream()))
+        return depth, tri_buf, bary
+
+    # -- lighting ----------------------------------------------------------------------------------
+    def phong_light(self, vertices: Tensor, normals: Tensor, ambient: float = 0.3, directional: float = 0.6,
+                    specular: float = 0.1, specular_exp: float = 5, color_ambient: Sequence[float] = (1, 1, 1),
+                    color_directional: Sequence[float] = (1, 1, 1), light_pos: Sequence[float] = (0, 0, 5),
+                    view_pos: Sequence[float] = (0, 0, 5)) -> Tensor:
+        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        n = _chk(normals, torch.float32, 3, "normals", self.torch_device)
+        cfg = _lib.LightC(float(ambient), float(directional), float(specular), float(specular_exp),
+                          (C.c_float * 3)(*color_ambient), (C.c_float * 3)(*color_directional),
+                          (C.c_float * 3)(*light_pos), (C.c_float * 3)(*view_pos))
+        out = torch.empty_like(v)
+        _lib.check(self._lib.dad3d_mesh_phong_light(self._handle, out.data_ptr(), v.data_ptr(), n.data_ptr(), v.shape[0],
+                                                    C.byref(cfg), self._stream()))
+        return out
+
+    def render(self, vertices: Tensor, bg: Tensor, **light_kwargs) -> Tensor:
+        """RenderPipeline.__call__ (lighting.py:37-71, texture=None) for a batch: normals -> Phong -> raster."""
+        normals = self.get_normal(vertices)
+        light = self.phong_light(vertices, normals, **light_kwargs)
+        return self.rasterize(vertices, light, bg)

@@ -1,0 +1,642 @@
+// C ABI of libdad3d_hip.so (include/dad3d.h): handle management, host-side operand packing, launches.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace dad3d {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+template <typename T>
+static dad3d_status upload(T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    if (!src.empty()) DAD3D_HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DAD3D_OK;
+}
+
+}  // namespace dad3d
+
+using namespace dad3d;
+
+// =================================================================================================
+// FLAME
+// =================================================================================================
+struct dad3d_flame {
+    int device = 0;
+    int n_verts = 0, n_betas = 0;
+    ParamLayout lay{};
+    int parents[kNumJoints]{};
+    int n_pose_feats = 0, pose_feat_first = 0;
+    int kgroups = 0, ksteps = 0;
+    int n_tiles = 0, n_tiles_pad8 = 0;
+    int max_shape = 300;
+    float image_size = 256.f;
+    float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
+    int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
+    int n_lmk = 0;
+    float *d_apack = nullptr, *d_imgc = nullptr;
+    int cap_nbb = 0;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+static dad3d_status flame_reserve(dad3d_flame* h, int nbb) {
+    if (nbb <= h->cap_nbb) return DAD3D_OK;
+    if (h->d_apack) (void)hipFree(h->d_apack);
+    if (h->d_imgc) (void)hipFree(h->d_imgc);
+    h->d_apack = h->d_imgc = nullptr;
+    h->cap_nbb = 0;
+    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_apack), (size_t)nbb * h->ksteps * 256 * sizeof(float)));
+    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_imgc), (size_t)nbb * kBlockImages * kImgConsts * sizeof(float)));
+    h->cap_nbb = nbb;
+    return DAD3D_OK;
+}
+
+extern "C" {
+
+const char* dad3d_last_error(void) { return g_last_error.c_str(); }
+void dad3d_clear_error(void) { g_last_error.clear(); }
+int dad3d_version(void) { return DAD3D_VERSION; }
+int dad3d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_consts* c, float image_size, int device,
+                                dad3d_flame** out) {
+    DAD3D_REQUIRE(m && c && out, "dad3d_flame_create: null argument");
+    *out = nullptr;
+    DAD3D_REQUIRE(m->v_template && m->shapedirs && m->posedirs && m->j_regressor && m->parents && m->lbs_weights,
+                  "dad3d_flame_create: null model array");
+    DAD3D_REQUIRE(m->n_joints == kNumJoints, "FLAME has %d joints, got %d", kNumJoints, m->n_joints);
+    DAD3D_REQUIRE(m->n_verts > 0 && m->n_betas == 400, "expected n_betas == 400 (MAX_SHAPE+MAX_EXPRESSION), got %d",
+                  m->n_betas);
+    // `assert v.shape[-1] == 6` (model/utils.py:93); translation/scale widths are fixed by head_mesh.py:39-42
+    DAD3D_REQUIRE(c->rotation == 6 && c->translation == 3 && c->scale == 1,
+                  "consts: rotation/translation/scale must be 6/3/1");
+    DAD3D_REQUIRE(c->shape >= 0 && c->shape <= 300 && c->expression >= 0 && c->expression <= 100,
+                  "consts: shape <= 300 and expression <= 100 required");
+    DAD3D_REQUIRE((c->jaw == 0 || c->jaw == 3) && (c->neck == 0 || c->neck == 3) && (c->eyeballs == 0 || c->eyeballs == 6),
+                  "consts: jaw/neck in {0,3}, eyeballs in {0,6}");
+    for (int j = 1; j < kNumJoints; ++j)
+        DAD3D_REQUIRE(m->parents[j] >= 0 && m->parents[j] < j, "parents[%d] = %d is not a valid kinematic tree", j,
+                      m->parents[j]);
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+
+    std::unique_ptr<dad3d_flame> h(new dad3d_flame);
+    h->device = device;
+    h->n_verts = m->n_verts;
+    h->n_betas = m->n_betas;
+    h->image_size = image_size;
+    ParamLayout& L = h->lay;
+    int cur = 0;
+    L.shape_off = cur, L.shape_n = c->shape, cur += c->shape;
+    L.expr_off = cur, L.expr_n = c->expression, cur += c->expression;
+    L.jaw_off = cur, L.jaw_n = c->jaw, cur += c->jaw;
+    L.rot_off = cur, cur += c->rotation;
+    L.eye_off = cur, L.eye_n = c->eyeballs, cur += c->eyeballs;
+    L.neck_off = cur, L.neck_n = c->neck, cur += c->neck;
+    L.trans_off = cur, cur += c->translation;
+    L.scale_off = cur, cur += c->scale;
+    L.n_params = cur;
+    for (int j = 0; j < kNumJoints; ++j) h->parents[j] = (j == 0) ? -1 : m->parents[j];
+
+    // Only the jaw can rotate when neck and eyeballs are size-0 inputs: their Rodrigues matrix is exactly
+    // I, so 27 of the 36 pose features are exactly 0 and their basis rows can be skipped (same result).
+    const bool jaw_only = (c->neck == 0 && c->eyeballs == 0);
+    h->n_pose_feats = jaw_only ? 9 : 36;
+    h->pose_feat_first = jaw_only ? 9 : 0;
+    const int k_used = 1 + h->n_betas + h->n_pose_feats;  // [template | betas | pose feature]
+    h->kgroups = (k_used + 15) / 16;
+    h->ksteps = h->kgroups * 4;
+    DAD3D_REQUIRE(h->kgroups == 26 || h->kgroups == 28, "unexpected basis depth %d", k_used);
+    const int V = m->n_verts, NB = m->n_betas;
+    h->n_tiles = (V + kTileVerts - 1) / kTileVerts;
+    h->n_tiles_pad8 = (h->n_tiles + 7) / 8 * 8;
+
+    // ---- pack the basis in MFMA B-fragment order: [tile][kgroup][wave][lane][4 k-steps] ----------
+    auto basis = [&](int k, int v, int comp) -> float {
+        if (k == 0) return m->v_template[(size_t)v * 3 + comp];
+        if (k <= NB) return m->shapedirs[((size_t)v * 3 + comp) * NB + (k - 1)];
+        const int f = h->pose_feat_first + (k - 1 - NB);
+        return m->posedirs[(size_t)f * 3 * V + (size_t)v * 3 + comp];
+    };
+    std::vector<float> bpack((size_t)h->n_tiles * h->kgroups * 4 * 64 * 4, 0.0f);
+    for (int t = 0; t < h->n_tiles; ++t)
+        for (int g = 0; g < h->kgroups; ++g)
+            for (int w = 0; w < 4; ++w)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int col = w * 16 + (lane & 15);
+                    const int v = t * kTileVerts + col / 3, comp = col % 3;
+                    if (col >= kTileVerts * 3 || v >= V) continue;
+                    float* dst = &bpack[((((size_t)t * h->kgroups + g) * 4 + w) * 64 + lane) * 4];
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = (g * 4 + i) * 4 + (lane >> 4);
+                        if (k < k_used) dst[i] = basis(k, v, comp);
+                    }
+                }
+
+    // ---- joints are linear in betas: J = J_regressor.v_template + (J_regressor.shapedirs).betas ----
+    std::vector<float> j0(3 * kNumJoints), jdirs((size_t)3 * kNumJoints * NB);
+    {
+        std::vector<double> acc((size_t)3 * kNumJoints * (NB + 1), 0.0);
+        for (int j = 0; j < kNumJoints; ++j)
+            for (int v = 0; v < V; ++v) {
+                const double r = m->j_regressor[(size_t)j * V + v];
+                if (r == 0.0) continue;
+                for (int comp = 0; comp < 3; ++comp) {
+                    double* a = &acc[((size_t)j * 3 + comp) * (NB + 1)];
+                    a[NB] += r * m->v_template[(size_t)v * 3 + comp];
+                    const float* sd = &m->shapedirs[((size_t)v * 3 + comp) * NB];
+                    for (int l = 0; l < NB; ++l) a[l] += r * sd[l];
+                }
+            }
+        for (int o = 0; o < 3 * kNumJoints; ++o) {
+            j0[o] = (float)acc[(size_t)o * (NB + 1) + NB];
+            for (int l = 0; l < NB; ++l) jdirs[(size_t)o * NB + l] = (float)acc[(size_t)o * (NB + 1) + l];
+        }
+    }
+    std::vector<float> w8((size_t)V * 8, 0.0f);
+    for (int v = 0; v < V; ++v)
+        for (int j = 0; j < kNumJoints; ++j) w8[(size_t)v * 8 + j] = m->lbs_weights[(size_t)v * kNumJoints + j];
+    std::vector<int> head(V, -1);
+
+    dad3d_status st;
+    if ((st = upload(&h->d_bpack, bpack)) || (st = upload(&h->d_jdirs, jdirs)) || (st = upload(&h->d_j0, j0)) ||
+        (st = upload(&h->d_w8, w8)) || (st = upload(&h->d_lmk_head, head)) ||
+        (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = flame_reserve(h.get(), 1))) {
+        dad3d_flame_destroy(h.release());
+        return st;
+    }
+    *out = h.release();
+    return DAD3D_OK;
+}
+
+void dad3d_flame_destroy(dad3d_flame* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    for (void* p : {(void*)h->d_bpack, (void*)h->d_jdirs, (void*)h->d_j0, (void*)h->d_w8, (void*)h->d_lmk_head,
+                    (void*)h->d_lmk_next, (void*)h->d_apack, (void*)h->d_imgc})
+        if (p) (void)hipFree(p);
+    for (auto& e : h->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete h;
+}
+
+int dad3d_flame_num_params(const dad3d_flame* h) { return h ? h->lay.n_params : -1; }
+int dad3d_flame_num_verts(const dad3d_flame* h) { return h ? h->n_verts : -1; }
+int dad3d_flame_num_landmarks(const dad3d_flame* h) { return h ? h->n_lmk : -1; }
+
+dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n) {
+    DAD3D_REQUIRE(h && n >= 0 && (idx || n == 0), "dad3d_flame_set_landmarks: bad argument");
+    std::vector<int> head(h->n_verts, -1), next(n, -1);
+    for (int s = n - 1; s >= 0; --s) {  // reverse walk: each vertex's chain comes out in ascending slot order
+        DAD3D_REQUIRE(idx[s] >= 0 && idx[s] < h->n_verts, "landmark index %lld out of range [0,%d)", (long long)idx[s],
+                      h->n_verts);
+        next[s] = head[idx[s]];
+        head[idx[s]] = s;
+    }
+    DeviceGuard guard(h->device);
+    int* d_next = nullptr;
+    dad3d_status st = upload(&d_next, next);
+    if (st) return st;
+    DAD3D_HIP_TRY(hipDeviceSynchronize());  // no decode may still be walking the old lists
+    DAD3D_HIP_TRY(hipMemcpy(h->d_lmk_head, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice));
+    (void)hipFree(h->d_lmk_next);
+    h->d_lmk_next = d_next;
+    h->n_lmk = n;
+    return DAD3D_OK;
+}
+
+dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+                                float* lmk_xy, int32_t* lmk_px, void* stream) {
+    DAD3D_REQUIRE(h, "dad3d_flame_decode: null handle");
+    DAD3D_REQUIRE(batch >= 0, "dad3d_flame_decode: negative batch");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(params, "dad3d_flame_decode: null params");  // `assert tensor_3dmm.ndim == 2` lives in the binding
+    DAD3D_REQUIRE(!((flags & DAD3D_FLIP_Z) && (flags & DAD3D_TO_2D)), "DAD3D_FLIP_Z needs a 3-component projection");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nbb = (batch + kBlockImages - 1) / kBlockImages;
+    if (nbb > h->cap_nbb) {
+        DAD3D_HIP_TRY(hipDeviceSynchronize());
+        dad3d_status st = flame_reserve(h, nbb);
+        if (st) return st;
+    }
+    PrologueArgs pa{};
+    pa.params = params;
+    pa.jdirs = h->d_jdirs;
+    pa.j0 = h->d_j0;
+    pa.apack = h->d_apack;
+    pa.imgc = h->d_imgc;
+    pa.lay = h->lay;
+    std::copy(h->parents, h->parents + kNumJoints, pa.parents);
+    pa.batch = batch;
+    pa.n_betas = h->n_betas;
+    pa.max_shape = h->max_shape;
+    pa.n_pose_feats = h->n_pose_feats;
+    pa.pose_feat_first = h->pose_feat_first;
+    pa.ksteps = h->ksteps;
+    pa.flags = flags;
+    dad3d_status st = launch_flame_prologue(pa, s);
+    if (st) return st;
+
+    DecodeArgs da{};
+    da.bpack = h->d_bpack;
+    da.apack = h->d_apack;
+    da.imgc = h->d_imgc;
+    da.weights8 = h->d_w8;
+    da.lmk_head = h->d_lmk_head;
+    da.lmk_next = h->d_lmk_next;
+    da.verts3d = verts3d;
+    da.proj = proj;
+    da.lmk_xy = lmk_xy;
+    da.lmk_px = lmk_px;
+    da.batch = batch;
+    da.nbb = nbb;
+    da.n_tiles = h->n_tiles;
+    da.n_tiles_pad8 = h->n_tiles_pad8;
+    da.n_verts = h->n_verts;
+    da.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
+    da.kgroups = h->kgroups;
+    da.image_size = h->image_size;
+    da.flags = flags;
+    if (h->profiling) {
+        if (h->ev_used == h->ev_pool.size()) {
+            hipEvent_t e0, e1;
+            DAD3D_HIP_TRY(hipEventCreate(&e0));
+            DAD3D_HIP_TRY(hipEventCreate(&e1));
+            h->ev_pool.emplace_back(e0, e1);
+        }
+        DAD3D_HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].first, s));
+    }
+    st = launch_flame_decode(da, s);
+    if (st) return st;
+    if (h->profiling) {
+        DAD3D_HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].second, s));
+        ++h->ev_used;
+    }
+    return DAD3D_OK;
+}
+
+dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
+                                     float* proj, float* lmk_xy, int32_t* lmk_px) {
+    DAD3D_REQUIRE(h, "dad3d_flame_decode_host: null handle");
+    DAD3D_REQUIRE(batch >= 0, "dad3d_flame_decode_host: negative batch");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(params, "dad3d_flame_decode_host: null params");
+    DeviceGuard guard(h->device);
+    const size_t B = batch, V = h->n_verts, P = h->lay.n_params, NL = h->n_lmk;
+    const size_t pc = (flags & DAD3D_TO_2D) ? 2 : 3;
+    const size_t n_par = B * P, n_v = verts3d ? B * V * 3 : 0, n_p = proj ? B * V * pc : 0;
+    const size_t n_lx = lmk_xy ? B * NL * 2 : 0, n_lp = lmk_px ? B * NL * 2 : 0;
+    float* d = nullptr;
+    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (n_par + n_v + n_p + n_lx + n_lp + 4) * sizeof(float)));
+    float* d_par = d;
+    float* d_v = n_v ? d_par + n_par : nullptr;
+    float* d_p = n_p ? d_par + n_par + n_v : nullptr;
+    float* d_lx = n_lx ? d_par + n_par + n_v + n_p : nullptr;
+    int32_t* d_lp = n_lp ? reinterpret_cast<int32_t*>(d_par + n_par + n_v + n_p + n_lx) : nullptr;
+    dad3d_status st = DAD3D_OK;
+    auto fail = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && st == DAD3D_OK) {
+            set_error("%s failed: %s", what, hipGetErrorString(e));
+            st = DAD3D_E_HIP;
+        }
+    };
+    fail(hipMemcpy(d_par, params, n_par * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(params)");
+    if (!st) st = dad3d_flame_decode(h, d_par, batch, flags, d_v, d_p, d_lx, d_lp, nullptr);
+    if (!st) fail(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (!st && (flags & DAD3D_MUTATE_PARAMS)) fail(hipMemcpy(params, d_par, n_par * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (!st && n_v) fail(hipMemcpy(verts3d, d_v, n_v * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (!st && n_p) fail(hipMemcpy(proj, d_p, n_p * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (!st && n_lx) fail(hipMemcpy(lmk_xy, d_lx, n_lx * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (!st && n_lp) fail(hipMemcpy(lmk_px, d_lp, n_lp * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy");
+    (void)hipFree(d);
+    return st;
+}
+
+dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batch, const float* pads_scale,
+                                         float pad_left, float pad_top, float scale, void* stream) {
+    DAD3D_REQUIRE(h && batch >= 0, "dad3d_flame_readjust_params: bad argument");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(params, "dad3d_flame_readjust_params: null params");
+    DeviceGuard guard(h->device);
+    return launch_readjust(params, batch, h->lay, pads_scale, pad_left, pad_top, scale, h->image_size,
+                           static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on) {
+    DAD3D_REQUIRE(h, "null handle");
+    h->profiling = on != 0;
+    return DAD3D_OK;
+}
+
+dad3d_status dad3d_flame_profile_read(dad3d_flame* h, double* total_ms, int* launches) {
+    DAD3D_REQUIRE(h && total_ms && launches, "null argument");
+    DeviceGuard guard(h->device);
+    double sum = 0.0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        DAD3D_HIP_TRY(hipEventSynchronize(h->ev_pool[i].second));
+        DAD3D_HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int)h->ev_used;
+    h->ev_used = 0;
+    return DAD3D_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Sim3DR
+// =================================================================================================
+struct dad3d_mesh {
+    int device = 0;
+    int ntri = 0, nver = 0;
+    int *d_tri = nullptr, *d_adj_ptr = nullptr, *d_adj_face = nullptr;
+    float* d_scratch = nullptr;
+    int scratch_batch = 0;
+    MeshDev dev() const { return MeshDev{d_tri, d_adj_ptr, d_adj_face, ntri, nver}; }
+};
+
+extern "C" {
+
+dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int device, dad3d_mesh** out) {
+    DAD3D_REQUIRE(out && ntri >= 0 && nver >= 0 && (tri || ntri == 0), "dad3d_mesh_create: bad argument");
+    *out = nullptr;
+    for (int i = 0; i < 3 * ntri; ++i)
+        DAD3D_REQUIRE(tri[i] >= 0 && tri[i] < nver, "triangle index %d out of range [0,%d)", tri[i], nver);
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    // vertex -> incident (face, corner) list; faces ascending, so a gather reproduces the serial
+    // scatter-add order of rasterize_kernel.cpp:188-198
+    std::vector<int> ptr(nver + 1, 0), face(3 * (size_t)ntri);
+    for (int i = 0; i < 3 * ntri; ++i) ++ptr[tri[i] + 1];
+    for (int v = 0; v < nver; ++v) ptr[v + 1] += ptr[v];
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int f = 0; f < ntri; ++f)
+        for (int c = 0; c < 3; ++c) face[fill[tri[3 * f + c]]++] = f;
+    std::unique_ptr<dad3d_mesh> m(new dad3d_mesh);
+    m->device = device;
+    m->ntri = ntri;
+    m->nver = nver;
+    std::vector<int> tri_v(tri, tri + 3 * (size_t)ntri);
+    dad3d_status st;
+    if ((st = upload(&m->d_tri, tri_v)) || (st = upload(&m->d_adj_ptr, ptr)) || (st = upload(&m->d_adj_face, face))) {
+        dad3d_mesh_destroy(m.release());
+        return st;
+    }
+    *out = m.release();
+    return DAD3D_OK;
+}
+
+void dad3d_mesh_destroy(dad3d_mesh* m) {
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_scratch})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+dad3d_status dad3d_mesh_get_normal(dad3d_mesh* m, float* ver_normal, const float* vertices, int batch, unsigned flags,
+                                   void* stream) {
+    DAD3D_REQUIRE(m && batch >= 0, "dad3d_mesh_get_normal: bad argument");
+    if (batch == 0 || m->nver == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(ver_normal && vertices, "dad3d_mesh_get_normal: null buffer");
+    DeviceGuard guard(m->device);
+    return launch_get_normal(m->dev(), ver_normal, vertices, batch, flags, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_get_tri_normal(dad3d_mesh* m, float* tri_normal, const float* vertices, int batch,
+                                       int norm_flg, void* stream) {
+    DAD3D_REQUIRE(m && batch >= 0, "dad3d_mesh_get_tri_normal: bad argument");
+    if (batch == 0 || m->ntri == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(tri_normal && vertices, "dad3d_mesh_get_tri_normal: null buffer");
+    DeviceGuard guard(m->device);
+    return launch_tri_normal(m->dev(), tri_normal, vertices, batch, norm_flg, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_get_ver_normal(dad3d_mesh* m, float* ver_normal, const float* tri_normal, int batch,
+                                       unsigned flags, void* stream) {
+    DAD3D_REQUIRE(m && batch >= 0, "dad3d_mesh_get_ver_normal: bad argument");
+    if (batch == 0 || m->nver == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(ver_normal && (tri_normal || m->ntri == 0), "dad3d_mesh_get_ver_normal: null buffer");
+    DeviceGuard guard(m->device);
+    return launch_ver_normal(m->dev(), ver_normal, tri_normal, batch, flags, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* vertices, const float* colors,
+                                  float* depth, int batch, int h, int w, int c, float alpha, int reverse,
+                                  void* stream) {
+    DAD3D_REQUIRE(m && batch >= 0 && h >= 0 && w >= 0 && c >= 0, "dad3d_mesh_rasterize: bad argument");
+    if (alpha != 1.0f) {
+        set_error("dad3d_mesh_rasterize: alpha=%g; only alpha == 1 is supported (the reference result for other "
+                  "values depends on triangle order)", (double)alpha);
+        return DAD3D_E_UNSUPPORTED;
+    }
+    if (batch == 0 || h == 0 || w == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(image && (vertices || m->ntri == 0) && (colors || m->ntri == 0 || c == 0),
+                  "dad3d_mesh_rasterize: null buffer");
+    DeviceGuard guard(m->device);
+    return launch_rasterize(m->dev(), image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse, 0,
+                            static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices, float* depth, int32_t* tri_buf,
+                                            float* bary, int batch, int h, int w, void* stream) {
+    DAD3D_REQUIRE(m && batch >= 0 && h >= 0 && w >= 0, "dad3d_mesh_rasterize_triangles: bad argument");
+    if (batch == 0 || h == 0 || w == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(depth && tri_buf && bary && (vertices || m->ntri == 0), "dad3d_mesh_rasterize_triangles: null buffer");
+    DeviceGuard guard(m->device);
+    return launch_rasterize(m->dev(), nullptr, vertices, nullptr, depth, tri_buf, bary, batch, h, w, 3, 0, 1,
+                            static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,
+                                    int batch, const dad3d_light* cfg, void* stream) {
+    DAD3D_REQUIRE(m && cfg && batch >= 0, "dad3d_mesh_phong_light: bad argument");
+    if (batch == 0 || m->nver == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(light && vertices && normals, "dad3d_mesh_phong_light: null buffer");
+    DeviceGuard guard(m->device);
+    if (batch > m->scratch_batch) {
+        DAD3D_HIP_TRY(hipDeviceSynchronize());
+        if (m->d_scratch) (void)hipFree(m->d_scratch);
+        m->d_scratch = nullptr;
+        m->scratch_batch = 0;
+        DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_scratch), (size_t)batch * 6 * sizeof(float)));
+        m->scratch_batch = batch;
+    }
+    return launch_phong(m->dev(), light, vertices, normals, batch, *cfg, m->d_scratch, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+// -------------------------------------------------------------------------------------------------
+// Exact-signature single-image host entry points (Sim3DR/lib/rasterize.h:84-100).
+// The reference API carries no vertex count for three of the five calls; it is derived from the
+// triangle list (max index + 1), which is all the GPU needs to stage.
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct HostMeshCache {
+    std::mutex mu;
+    dad3d_mesh* mesh = nullptr;
+    uint64_t hash = 0;
+    int ntri = -1, nver = -1;
+    ~HostMeshCache() { /* process teardown: the HIP runtime may already be gone; leak on purpose */ }
+};
+HostMeshCache g_cache;
+
+int compat_device() {
+    const char* e = std::getenv("DAD3D_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+
+uint64_t fnv1a(const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
+int max_index_plus_one(const int* tri, int ntri) {
+    int mx = -1;
+    for (int i = 0; i < 3 * ntri; ++i) mx = std::max(mx, tri[i]);
+    return mx + 1;
+}
+
+// topology is static across calls in practice (one mesh, many frames): rebuild only when it changes
+dad3d_mesh* cached_mesh(const int* tri, int ntri, int nver) {
+    const uint64_t hsh = fnv1a(tri, sizeof(int) * 3 * (size_t)ntri);
+    if (g_cache.mesh && g_cache.hash == hsh && g_cache.ntri == ntri && g_cache.nver == nver) return g_cache.mesh;
+    if (g_cache.mesh) dad3d_mesh_destroy(g_cache.mesh);
+    g_cache.mesh = nullptr;
+    if (dad3d_mesh_create(tri, ntri, nver, compat_device(), &g_cache.mesh) != DAD3D_OK) return nullptr;
+    g_cache.hash = hsh;
+    g_cache.ntri = ntri;
+    g_cache.nver = nver;
+    return g_cache.mesh;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    bool alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 4)) == hipSuccess; }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+bool h2d(void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; }
+bool d2h(void* h, const void* d, size_t n) { return n == 0 || hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess; }
+
+}  // namespace
+
+extern "C" {
+
+void dad3d_sim3dr_get_tri_normal(float* tri_normal, float* vertices, int* triangles, int ntri, int norm_flg) {
+    if (ntri <= 0) return;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    const int nver = max_index_plus_one(triangles, ntri);
+    dad3d_mesh* m = cached_mesh(triangles, ntri, nver);
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    DevBuf dv, dn;
+    const size_t vb = sizeof(float) * 3 * (size_t)nver, nb = sizeof(float) * 3 * (size_t)ntri;
+    if (!dv.alloc(vb) || !dn.alloc(nb) || !h2d(dv.p, vertices, vb)) return set_error("sim3dr compat: staging failed");
+    if (dad3d_mesh_get_tri_normal(m, (float*)dn.p, (const float*)dv.p, 1, norm_flg, nullptr)) return;
+    if (hipDeviceSynchronize() != hipSuccess || !d2h(tri_normal, dn.p, nb)) set_error("sim3dr compat: readback failed");
+}
+
+void dad3d_sim3dr_get_ver_normal(float* ver_normal, float* tri_normal, int* triangles, int nver, int ntri) {
+    if (nver <= 0) return;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    dad3d_mesh* m = cached_mesh(triangles, std::max(ntri, 0), nver);
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    DevBuf dt, dn;
+    const size_t tb = sizeof(float) * 3 * (size_t)std::max(ntri, 0), nb = sizeof(float) * 3 * (size_t)nver;
+    if (!dt.alloc(tb) || !dn.alloc(nb) || !h2d(dt.p, tri_normal, tb) || !h2d(dn.p, ver_normal, nb))
+        return set_error("sim3dr compat: staging failed");
+    if (dad3d_mesh_get_ver_normal(m, (float*)dn.p, (const float*)dt.p, 1, DAD3D_NORMAL_ACCUMULATE, nullptr)) return;
+    if (hipDeviceSynchronize() != hipSuccess || !d2h(ver_normal, dn.p, nb)) set_error("sim3dr compat: readback failed");
+}
+
+void dad3d_sim3dr_get_normal(float* ver_normal, float* vertices, int* triangles, int nver, int ntri) {
+    if (nver <= 0) return;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    dad3d_mesh* m = cached_mesh(triangles, std::max(ntri, 0), nver);
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    DevBuf dv, dn;
+    const size_t nb = sizeof(float) * 3 * (size_t)nver;
+    if (!dv.alloc(nb) || !dn.alloc(nb) || !h2d(dv.p, vertices, nb) || !h2d(dn.p, ver_normal, nb))
+        return set_error("sim3dr compat: staging failed");
+    if (dad3d_mesh_get_normal(m, (float*)dn.p, (const float*)dv.p, 1, DAD3D_NORMAL_ACCUMULATE, nullptr)) return;
+    if (hipDeviceSynchronize() != hipSuccess || !d2h(ver_normal, dn.p, nb)) set_error("sim3dr compat: readback failed");
+}
+
+void dad3d_sim3dr_rasterize_triangles(float* vertices, int* triangles, float* depth_buffer, int* triangle_buffer,
+                                      float* barycentric_weight, int ntri, int h, int w) {
+    if (ntri <= 0 || h <= 0 || w <= 0) return;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    const int nver = max_index_plus_one(triangles, ntri);
+    dad3d_mesh* m = cached_mesh(triangles, ntri, nver);
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    DevBuf dv, dd, dt, db;
+    const size_t vb = sizeof(float) * 3 * (size_t)nver, pb = (size_t)h * w;
+    if (!dv.alloc(vb) || !dd.alloc(pb * 4) || !dt.alloc(pb * 4) || !db.alloc(pb * 12) || !h2d(dv.p, vertices, vb) ||
+        !h2d(dd.p, depth_buffer, pb * 4) || !h2d(dt.p, triangle_buffer, pb * 4) || !h2d(db.p, barycentric_weight, pb * 12))
+        return set_error("sim3dr compat: staging failed");
+    if (dad3d_mesh_rasterize_triangles(m, (const float*)dv.p, (float*)dd.p, (int32_t*)dt.p, (float*)db.p, 1, h, w, nullptr))
+        return;
+    if (hipDeviceSynchronize() != hipSuccess || !d2h(depth_buffer, dd.p, pb * 4) || !d2h(triangle_buffer, dt.p, pb * 4) ||
+        !d2h(barycentric_weight, db.p, pb * 12))
+        set_error("sim3dr compat: readback failed");
+}
+
+void dad3d_sim3dr_rasterize(unsigned char* image, float* vertices, int* triangles, float* colors, float* depth_buffer,
+                            int ntri, int h, int w, int c, float alpha, int reverse) {
+    if (ntri <= 0 || h <= 0 || w <= 0) return;
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    const int nver = max_index_plus_one(triangles, ntri);
+    dad3d_mesh* m = cached_mesh(triangles, ntri, nver);
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    DevBuf dv, dc, dd, di;
+    const size_t vb = sizeof(float) * 3 * (size_t)nver, cb = sizeof(float) * (size_t)c * nver, pb = (size_t)h * w;
+    if (!dv.alloc(vb) || !dc.alloc(cb) || !dd.alloc(pb * 4) || !di.alloc(pb * c) || !h2d(dv.p, vertices, vb) ||
+        !h2d(dc.p, colors, cb) || !h2d(dd.p, depth_buffer, pb * 4) || !h2d(di.p, image, pb * c))
+        return set_error("sim3dr compat: staging failed");
+    if (dad3d_mesh_rasterize(m, (uint8_t*)di.p, (const float*)dv.p, (const float*)dc.p, (float*)dd.p, 1, h, w, c, alpha,
+                             reverse, nullptr))
+        return;
+    if (hipDeviceSynchronize() != hipSuccess || !d2h(image, di.p, pb * c) || !d2h(depth_buffer, dd.p, pb * 4))
+        set_error("sim3dr compat: readback failed");
+}
+
+}  // extern "C"

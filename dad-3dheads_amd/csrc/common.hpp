@@ -1,0 +1,134 @@
+// Shared host-side declarations for libdad3d_hip.so (gfx950 only; no portability layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/dad3d.h"
+
+namespace dad3d {
+
+void set_error(const char* fmt, ...);
+
+#define DAD3D_HIP_TRY(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            ::dad3d::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                               __LINE__);                                                        \
+            return DAD3D_E_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define DAD3D_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::dad3d::set_error(__VA_ARGS__); \
+            return DAD3D_E_INVALID;         \
+        }                                   \
+    } while (0)
+
+// RAII: make `device` current for the scope of a C-ABI call, restore afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// FLAME decode: geometry of the packed operands (see DESIGN.md "Data layout in HBM")
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileVerts = 21;   // vertices per column tile: 63 basis columns + 1 zero pad = 64
+constexpr int kTileCols = 64;    // 4 waves x one 16-wide MFMA column block
+constexpr int kBlockImages = 64; // images (GEMM rows) per workgroup: 4 MFMA row blocks of 16
+constexpr int kImgConsts = 80;   // floats per image in the per-image constant block
+constexpr int kNumJoints = 5;    // FLAME: global, neck, jaw, left eye, right eye
+constexpr int kOutStride = 68;   // LDS row stride of the accumulator tile (conflict-free ds_write_b32)
+
+// Offsets into one params row, `FlameParams.from_3dmm` order (flame.py:48-73).
+struct ParamLayout {
+    int n_params;
+    int shape_off, shape_n;
+    int expr_off, expr_n;
+    int jaw_off, jaw_n;
+    int rot_off;
+    int eye_off, eye_n;
+    int neck_off, neck_n;
+    int trans_off;
+    int scale_off;
+};
+
+struct PrologueArgs {
+    float* params;          // [B,P]
+    const float* jdirs;     // [15][n_betas]  J_regressor . shapedirs
+    const float* j0;        // [15]           J_regressor . v_template
+    float* apack;           // [nbb][ksteps][64 lanes][4 row blocks]
+    float* imgc;            // [nbb*64][kImgConsts]
+    ParamLayout lay;
+    int parents[kNumJoints];
+    int batch;
+    int n_betas;   // 400
+    int max_shape; // 300
+    int n_pose_feats; // 9 (jaw only) or 36
+    int pose_feat_first; // 9 or 0
+    int ksteps;    // K/4, multiple of 4
+    unsigned flags;
+};
+
+struct DecodeArgs {
+    const float* bpack;    // [n_tiles][kgroups][4 waves][64 lanes][4]
+    const float* apack;
+    const float* imgc;
+    const float* weights8; // [V][8] skinning weights, zero padded
+    const int* lmk_head;   // [V] first landmark slot of a vertex or -1
+    const int* lmk_next;   // [n_lmk] next slot with the same vertex or -1
+    float* verts3d;        // [B,V,3] or null
+    float* proj;           // [B,V,2|3] or null
+    float* lmk_xy;         // [B,n_lmk,2] or null
+    int32_t* lmk_px;       // [B,n_lmk,2] or null
+    int batch, nbb, n_tiles, n_tiles_pad8, n_verts, n_lmk;
+    int kgroups;
+    float image_size;
+    unsigned flags;
+};
+
+dad3d_status launch_flame_prologue(const PrologueArgs& a, hipStream_t s);
+dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s);
+dad3d_status launch_readjust(float* params, int batch, ParamLayout lay, const float* pads_scale, float pad_left,
+                             float pad_top, float scale, float img_size, hipStream_t s);
+size_t flame_decode_lds_bytes(int kgroups);
+
+// ---------------------------------------------------------------------------------------------
+// Sim3DR
+// ---------------------------------------------------------------------------------------------
+struct MeshDev {
+    const int* tri;       // [ntri,3]
+    const int* adj_ptr;   // [nver+1]   CSR rows: (face, corner) incidences of a vertex, ascending face order
+    const int* adj_face;  // [3*ntri]
+    int ntri, nver;
+};
+
+dad3d_status launch_tri_normal(const MeshDev& m, float* tri_normal, const float* vertices, int batch, int norm_flg,
+                               hipStream_t s);
+dad3d_status launch_ver_normal(const MeshDev& m, float* ver_normal, const float* tri_normal, int batch,
+                               unsigned flags, hipStream_t s);
+dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float* vertices, int batch, unsigned flags,
+                               hipStream_t s);
+dad3d_status launch_rasterize(const MeshDev& m, uint8_t* image, const float* vertices, const float* colors,
+                              float* depth, int32_t* tri_buf, float* bary, int batch, int h, int w, int c,
+                              int reverse, int mode, hipStream_t s);
+dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals, int batch,
+                          const dad3d_light& cfg, float* scratch, hipStream_t s);
+
+}  // namespace dad3d

@@ -1,0 +1,183 @@
+/*
+ * dad3d.h -- C ABI of libdad3d_hip.so, the MI355X (gfx950) implementation of the DAD-3DNet
+ * mesh-decode hot path: FLAME/HeadMesh decode -> weak-perspective projection -> landmark gather,
+ * and the Sim3DR vertex-normal / z-buffer rasterisation loops.
+ *
+ * Plain C, no torch types: pointers + sizes only. Unless a function says "host", every buffer is a
+ * DEVICE pointer (HBM of the device the handle was created on) and every call is ASYNCHRONOUS on the
+ * `hipStream_t` passed as `void* stream` (NULL = the default stream). Every function returns a
+ * dad3d_status; nothing throws across the boundary. dad3d_last_error() gives a thread-local message.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef DAD3D_H_
+#define DAD3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAD3D_VERSION 100 /* 0.1.0 */
+
+typedef enum dad3d_status {
+    DAD3D_OK = 0,
+    DAD3D_E_INVALID = 1,     /* bad argument (NULL, negative size, shape mismatch) */
+    DAD3D_E_HIP = 2,         /* a HIP runtime call failed; see dad3d_last_error() */
+    DAD3D_E_UNSUPPORTED = 3, /* valid in the reference but not implemented here (documented) */
+    DAD3D_E_NOMEM = 4
+} dad3d_status;
+
+const char* dad3d_last_error(void);
+void dad3d_clear_error(void); /* reset the thread-local message to "" */
+int dad3d_version(void);
+/* Number of visible HIP devices (0 when there is none). Host-only, launches nothing. */
+int dad3d_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * FLAME / HeadMesh decode
+ * ---------------------------------------------------------------------------------------------- */
+
+/* HOST pointers to the FLAME constants exactly as `FLAMELayer.__init__` registers them
+ * (model_training/model/flame.py:124-180), all C-contiguous fp32 unless noted. */
+typedef struct dad3d_flame_model {
+    int32_t n_verts;          /* V = 5023 */
+    int32_t n_betas;          /* MAX_SHAPE + MAX_EXPRESSION = 400 (flame.py:107-108) */
+    int32_t n_joints;         /* J = 5 */
+    const float* v_template;  /* [V,3]                       flame.py:157 */
+    const float* shapedirs;   /* [V,3,n_betas]               flame.py:160-163 */
+    const float* posedirs;    /* [(J-1)*9, 3V] (already reshaped+transposed, flame.py:169-173) */
+    const float* j_regressor; /* [J,V] dense                 flame.py:165-166 */
+    const int32_t* parents;   /* [J], root = -1              flame.py:175-178 */
+    const float* lbs_weights; /* [V,J]                       flame.py:180 */
+} dad3d_flame_model;
+
+/* The `constants` dict of dad_3dnet.yaml:4-12 / FLAME_CONSTS (flame.py:17-26). The params vector is
+ * sliced in `FlameParams.from_3dmm` order (flame.py:48-73):
+ *   shape | expression | jaw | rotation | eyeballs | neck | translation | scale                   */
+typedef struct dad3d_flame_consts {
+    int32_t shape, expression, jaw, rotation, eyeballs, neck, translation, scale;
+} dad3d_flame_consts;
+
+typedef struct dad3d_flame dad3d_flame; /* opaque: packed basis + scratch resident in HBM */
+
+/* decode flags */
+#define DAD3D_ZERO_ROTATION 0x1u /* skip the 6-DoF rotation        (flame.py:225 `zero_rot`) */
+#define DAD3D_TO_2D 0x2u         /* `proj` is [B,V,2] not [B,V,3]  (head_mesh.py:44-45 `to_2d`) */
+#define DAD3D_MUTATE_PARAMS 0x4u /* write translation z := 0 back into `params`, the side effect of
+                                    HeadMesh.reprojected_vertices (head_mesh.py:41) */
+#define DAD3D_FLIP_Z 0x8u        /* negate proj z (inference/pncc_estimator.py:88), needs !TO_2D */
+
+/* Upload + repack the model for `device`. Replaces FLAMELayer.__init__ (flame.py:124-180) and
+ * HeadMesh.__init__ (head_mesh.py:10-22). `image_size` is HeadMesh._image_size (256). */
+dad3d_status dad3d_flame_create(const dad3d_flame_model* model, const dad3d_flame_consts* consts, float image_size,
+                                int device, dad3d_flame** out);
+void dad3d_flame_destroy(dad3d_flame* h);
+
+/* Number of floats per params row (sum of the consts; 413 for dad_3dnet.yaml). */
+int dad3d_flame_num_params(const dad3d_flame* h);
+int dad3d_flame_num_verts(const dad3d_flame* h);
+
+/* Ordered landmark index list (HOST int64, e.g. the 445 list of model_training/utils.py:62-105 or the
+ * per-file lists demo_utils.py:44-46 walks). Duplicates allowed. Replaces np.take(..., indices, axis=0). */
+dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* indices, int n);
+int dad3d_flame_num_landmarks(const dad3d_flame* h);
+
+/* One fused decode of B parameter rows. Any output pointer may be NULL (not produced).
+ *   params  [B,P] fp32 (read; tz written when DAD3D_MUTATE_PARAMS)
+ *   verts3d [B,V,3]  == HeadMesh.vertices_3d(params, zero_rotation)            head_mesh.py:28-31
+ *   proj    [B,V,2|3]== HeadMesh.reprojected_vertices(params, to_2d)           head_mesh.py:33-46
+ *                       (always rotated; DAD3D_ZERO_ROTATION applies to verts3d only, as in the reference)
+ *   lmk_xy  [B,n,2] fp32 = proj[:, idx, :2]
+ *   lmk_px  [B,n,2] int32 = projected.astype(int)[idx]  (truncation)           demo_utils.py:42,46
+ * The reference needs two full decodes for verts3d + proj (predictor.py:136-137); this is one. */
+dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+                                float* lmk_xy, int32_t* lmk_px, void* stream);
+
+/* Same, HOST buffers in and out (synchronous; PCIe-inclusive convenience for non-HIP callers). */
+dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
+                                     float* proj, float* lmk_xy, int32_t* lmk_px);
+
+/* predictor.readjust_3dmm_to_the_input_image (predictor.py:154-176), in place on device params:
+ *   s' = (s+1)/scale - 1 ;  t' = (t + 1 - [pad_left,pad_top,0]*2/img_size)/scale - 1
+ * `pads_scale` is a DEVICE array [B,3] = (pad_left, pad_top, scale) per row, or NULL with the three
+ * scalars applied to every row. */
+dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batch, const float* pads_scale,
+                                         float pad_left, float pad_top, float scale, void* stream);
+
+/* Timing aid for bench.py: when enabled, every decode brackets its dominant kernel (the fused
+ * blend-shape/skinning kernel) with hipEvents on the launch stream; `_read` synchronises, returns the
+ * summed milliseconds and launch count since the last `_read`, and resets them. */
+dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on);
+dad3d_status dad3d_flame_profile_read(dad3d_flame* h, double* total_ms, int* launches);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sim3DR: vertex normals + z-buffer rasterisation
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct dad3d_mesh dad3d_mesh; /* opaque: triangle list + vertex->face adjacency in HBM */
+
+/* `triangles` HOST int32 [ntri,3] (numpy intc, as Sim3DR/lib/rasterize.pyx:63-69 requires). */
+dad3d_status dad3d_mesh_create(const int32_t* triangles, int ntri, int nver, int device, dad3d_mesh** out);
+void dad3d_mesh_destroy(dad3d_mesh* m);
+
+#define DAD3D_NORMAL_ACCUMULATE 0x1u /* add onto the existing content of `ver_normal` like the C function does;
+                                        default = start from zero like Sim3DR/Sim3DR.py:9 */
+/* Batched `_get_normal` (Sim3DR/lib/rasterize_kernel.cpp:158-215; rasterize.h:92).
+ *   vertices [B,nver,3] fp32 -> ver_normal [B,nver,3] fp32. Bit-exact with the reference. */
+dad3d_status dad3d_mesh_get_normal(dad3d_mesh* m, float* ver_normal, const float* vertices, int batch,
+                                   unsigned flags, void* stream);
+/* Batched `_get_tri_normal` (rasterize_kernel.cpp:87-120): tri_normal [B,ntri,3]. */
+dad3d_status dad3d_mesh_get_tri_normal(dad3d_mesh* m, float* tri_normal, const float* vertices, int batch,
+                                       int norm_flg, void* stream);
+/* Batched `_get_ver_normal` (rasterize_kernel.cpp:125-153): tri_normal [B,ntri,3] -> ver_normal [B,nver,3]. */
+dad3d_status dad3d_mesh_get_ver_normal(dad3d_mesh* m, float* ver_normal, const float* tri_normal, int batch,
+                                       unsigned flags, void* stream);
+
+/* Batched `_rasterize` (rasterize_kernel.cpp:219-292; rasterize.h:98-100).
+ *   image    [B,h,w,c] uint8, read-modify-write (background in, render out)
+ *   vertices [B,nver,3] fp32 (pixel x, pixel y, depth); colors [B,nver,c] fp32 in [0,1]
+ *   depth    [B,h,w] fp32 in/out, or NULL = start from -1e8 (Sim3DR/Sim3DR.py:23) and discard
+ *   alpha must be 1 (the only value Python can reach: Sim3DR.py:27-28, rasterize.pyx:95); anything else
+ *   returns DAD3D_E_UNSUPPORTED because the reference result is then triangle-order dependent.
+ * Bit-exact with the reference for alpha == 1: strict-interior test, `>` depth test, ties to the
+ * lowest triangle index, (unsigned char) truncation. */
+dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* vertices, const float* colors,
+                                  float* depth, int batch, int h, int w, int c, float alpha, int reverse,
+                                  void* stream);
+/* Batched `_rasterize_triangles` (rasterize_kernel.cpp:295-353): depth [B,h,w] in/out (required),
+ * triangle_buffer [B,h,w] int32 and barycentric [B,h,w,3] fp32 written where a triangle wins. */
+dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices, float* depth,
+                                            int32_t* triangle_buffer, float* barycentric, int batch, int h, int w,
+                                            void* stream);
+
+/* Per-vertex Phong lighting of Sim3DR/lighting.py:37-62 (`RenderPipeline.__call__`, texture=None):
+ * normals [B,nver,3] + vertices [B,nver,3] -> light [B,nver,3] in [0,1]. Float op order follows the
+ * numpy code; agreement with numpy is to rounding (pow), not bitwise. */
+typedef struct dad3d_light {
+    float intensity_ambient, intensity_directional, intensity_specular, specular_exp;
+    float color_ambient[3], color_directional[3], light_pos[3], view_pos[3];
+} dad3d_light;
+dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,
+                                    int batch, const dad3d_light* cfg, void* stream);
+
+/* Single-image HOST entry points with the argument lists of Sim3DR/lib/rasterize.h:84-100 (`bool` spelled
+ * `int` for C). libdad3d_hip.so additionally exports the C++-linkage symbols `_get_tri_normal`,
+ * `_get_ver_normal`, `_get_normal`, `_rasterize_triangles`, `_rasterize` with the reference's exact
+ * prototypes (csrc/sim3dr_compat.cpp), so Sim3DR/lib/rasterize.pyx links against it unchanged (see
+ * INTEGRATION.md). They stage through the GPU synchronously on device $DAD3D_DEVICE (default 0); the
+ * vertex count the reference API omits is derived from the triangle list. The reference signatures
+ * return void: failures are reported through dad3d_last_error() and leave the outputs untouched. */
+void dad3d_sim3dr_get_tri_normal(float* tri_normal, float* vertices, int* triangles, int ntri, int norm_flg);
+void dad3d_sim3dr_get_ver_normal(float* ver_normal, float* tri_normal, int* triangles, int nver, int ntri);
+void dad3d_sim3dr_get_normal(float* ver_normal, float* vertices, int* triangles, int nver, int ntri);
+void dad3d_sim3dr_rasterize_triangles(float* vertices, int* triangles, float* depth_buffer, int* triangle_buffer,
+                                      float* barycentric_weight, int ntri, int h, int w);
+void dad3d_sim3dr_rasterize(unsigned char* image, float* vertices, int* triangles, float* colors,
+                            float* depth_buffer, int ntri, int h, int w, int c, float alpha, int reverse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAD3D_H_ */

@@ -1,0 +1,193 @@
+"""GPU: the HIP FLAME decode (through the C ABI) against the CPU oracle and the reference-generated goldens.
+Tolerance from BASELINE.json north_star: vertex coordinates within 1e-4 abs fp32, landmark indices bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from dad_3dheads_amd import _lib, landmarks, synthetic
+from dad_3dheads_amd.head_mesh import HeadMesh
+from oracle import flame_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hm(flame_model, static):
+    return HeadMesh(flame_model=flame_model, landmarks=landmarks.canonical("445", static), static=static, device=0)
+
+
+def oracle_outputs(consts, params_np, to_2d=True):
+    p = torch.from_numpy(params_np.copy())
+    v3d = flame_ref.vertices_3d(consts, p)
+    proj = flame_ref.reprojected_vertices(consts, p, to_2d=to_2d)
+    return v3d.numpy(), proj.numpy(), p.numpy()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 4, 17, 64, 65, 130])
+def test_decode_matches_oracle(hm, flame_consts, static, batch):
+    params = synthetic.synthetic_params(batch, seed=1000 + batch)
+    v_ref, p_ref, after = oracle_outputs(flame_consts, params, to_2d=False)
+    dev = torch.from_numpy(params).cuda()
+    out = hm.decode(dev, to_2d=False, landmarks=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    assert np.abs(out["verts3d"].cpu().numpy() - v_ref).max() < TOL
+    assert np.abs(out["proj"].cpu().numpy() - p_ref).max() < TOL
+    assert np.array_equal(dev.cpu().numpy(), after)  # tz := 0 written back, nothing else touched
+    # landmark gather is an exact gather of the projection (index list bit-exact)
+    lmk = torch.from_numpy(landmarks.canonical("445", static)).cuda()
+    assert torch.equal(out["lmk_xy"], out["proj"][:, lmk, :2])
+    assert torch.equal(out["lmk_px"], out["proj"][:, lmk, :2].to(torch.int32))  # truncation toward zero
+    # int pixels vs the oracle: equal, or off by one only where the coordinate is within TOL of an integer
+    ref_px = np.take(p_ref[..., :2].astype(int), landmarks.canonical("445", static), axis=1)
+    diff = out["lmk_px"].cpu().numpy() - ref_px
+    ref_xy = p_ref[:, landmarks.canonical("445", static), :2]
+    near_int = np.abs(ref_xy - np.round(ref_xy)) < 2 * TOL
+    assert np.all((diff == 0) | ((np.abs(diff) == 1) & near_int))
+
+
+def test_decode_matches_reference_goldens(hm, decode_golden, static):
+    g = decode_golden
+    dev = torch.from_numpy(g["b2_params"].copy()).cuda()
+    out = hm.decode(dev, to_2d=False)
+    zero = hm.decode(dev, proj=False, landmarks=False, zero_rotation=True)["verts3d"]
+    torch.cuda.synchronize()
+    assert np.abs(out["verts3d"].cpu().numpy() - g["b2_v3d"]).max() < TOL
+    assert np.abs(zero.cpu().numpy() - g["b2_v3d_zero_rot"]).max() < TOL
+    assert np.abs(out["proj"].cpu().numpy() - g["b2_proj3"]).max() < TOL
+    assert np.array_equal(dev.cpu().numpy(), g["b2_params_after"])
+
+    dev = torch.from_numpy(g["b64_params"].copy()).cuda()
+    out = hm.decode(dev, to_2d=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    sub = g["b64_subset"]
+    assert out["proj"].shape == (64, 5023, 2)
+    assert np.abs(out["verts3d"].cpu().numpy()[:, sub] - g["b64_v3d_sub"]).max() < TOL
+    assert np.abs(out["proj"].cpu().numpy()[:, sub] - g["b64_proj_sub"]).max() < TOL
+    assert np.abs(out["lmk_xy"].cpu().numpy() - g["b64_lmk_xy"]).max() < TOL
+    diff = out["lmk_px"].cpu().numpy() - g["b64_lmk_px"]
+    near_int = np.abs(g["b64_lmk_xy"] - np.round(g["b64_lmk_xy"])) < 2 * TOL
+    assert np.all((diff == 0) | ((np.abs(diff) == 1) & near_int))
+
+
+def test_decode_edge_cases_match_goldens(hm, decode_golden):
+    g = decode_golden
+    dev = torch.from_numpy(g["edge_params"].copy()).cuda()
+    out = hm.decode(dev, to_2d=False, landmarks=False)
+    zero = hm.decode(dev, proj=False, landmarks=False, zero_rotation=True)["verts3d"]
+    torch.cuda.synchronize()
+    sub = g["edge_subset"]
+    assert np.abs(out["verts3d"].cpu().numpy()[:, sub] - g["edge_v3d_sub"]).max() < TOL
+    assert np.abs(zero.cpu().numpy()[:, sub] - g["edge_v3d_zero_rot_sub"]).max() < TOL
+    # row 5 has 4x coefficients: coordinates are ~4x larger, so is the fp32 rounding; still inside 1e-4 * scale
+    err = np.abs(out["proj"].cpu().numpy()[:, sub] - g["edge_proj3_sub"])
+    assert err[:5].max() < TOL and err[5].max() < 4 * TOL
+    assert np.array_equal(dev.cpu().numpy(), g["edge_params_after"])
+    assert torch.all(out["verts3d"][3] == 0) and torch.all(out["verts3d"][4] == 0)  # degenerate 6-DoF -> R = 0
+
+
+def test_head_mesh_reference_surface(hm, flame_consts):
+    # CPU tensors in -> CPU tensors out, with the reference's side effect on the caller's tensor
+    params = torch.from_numpy(synthetic.synthetic_params(3, seed=77)[:2].copy())
+    ref = params.clone()
+    v_ref = flame_ref.vertices_3d(flame_consts, ref)
+    p_ref = flame_ref.reprojected_vertices(flame_consts, ref, to_2d=True)
+    v = hm.vertices_3d(params)
+    assert v.device.type == "cpu" and v.shape == (2, 5023, 3) and (v - v_ref).abs().max() < TOL
+    assert params[0, 411] != 0
+    p2 = hm.reprojected_vertices(params_3dmm=params, to_2d=True)
+    assert p2.shape == (2, 5023, 2) and (p2 - p_ref).abs().max() < TOL
+    assert (params[:, 411] == 0).all() and torch.equal(params, ref)
+    assert hm.reprojected_vertices(params, to_2d=False).shape == (2, 5023, 3)
+    z = hm.vertices_3d(params, zero_rotation=True)
+    assert (z - flame_ref.vertices_3d(flame_consts, params.clone(), zero_rotation=True)).abs().max() < TOL
+    with pytest.raises(AssertionError):
+        hm.vertices_3d(params[0])
+    # FLAMELayer.forward over FlameParams views (pncc_estimator / losses call style)
+    fp = hm.flame_params(params)
+    assert (hm.flame.forward(fp, zero_rot=False) - v_ref).abs().max() < TOL
+    assert hm.flame.faces.shape == (9976, 3) and hm.flame.faces_tensor.dtype == torch.long
+    assert hm.flame.indices_2d.shape == (191,)
+    adj = hm.adjust_3dmm_to_paddings(params.clone(), [10, 0, 20, 0])
+    assert adj.shape == (2, 413)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        hm.vertices_3d(params.clone().requires_grad_(True))
+
+
+def test_linearity_and_determinism_at_full_size(hm):
+    """Size-independent properties at B=256 (BASELINE config 3): identical rows give identical outputs, the
+    decode is deterministic run to run, and zero betas reproduce the rigidly-posed template."""
+    base = synthetic.synthetic_params(256, seed=5)
+    base[128:] = base[:128]  # second half duplicates the first: different workgroups, same math
+    dev = torch.from_numpy(base).cuda()
+    a = hm.decode(dev.clone(), to_2d=True)
+    b = hm.decode(dev.clone(), to_2d=True)
+    torch.cuda.synchronize()
+    for k in ("verts3d", "proj", "lmk_xy"):
+        assert torch.equal(a[k], b[k])
+        assert torch.equal(a[k][:128], a[k][128:])
+    # scale/translation act affinely on the projection: proj(s, t) = (R v s + t + 1) * 128
+    p = torch.from_numpy(synthetic.synthetic_params(4, seed=6)).cuda()
+    out = hm.decode(p.clone(), to_2d=True, landmarks=False)
+    s = (p[:, 412] + 1).clamp_min(1e-8)[:, None, None]
+    t = p[:, None, 409:411]
+    expect = (out["verts3d"][..., :2] * s + t + 1.0) / 2.0 * 256
+    assert (out["proj"] - expect).abs().max() < 1e-3
+
+
+def test_full_pose_config_neck_and_eyeballs(flame_model, static):
+    """A constants dict that feeds neck + eyeball poses (K = 437 -> the 28-group kernel instantiation)."""
+    consts = {"shape": 300, "expression": 100, "jaw": 3, "rotation": 6, "eyeballs": 6, "neck": 3, "translation": 3, "scale": 1}
+    hm2 = HeadMesh(flame_config=consts, flame_model=flame_model, static=static, device=0)
+    rng = np.random.default_rng(3)
+    base = synthetic.synthetic_params(5, seed=9)
+    p = np.concatenate([base[:, :409], 0.2 * rng.standard_normal((5, 9)).astype(np.float32), base[:, 409:]], axis=1)
+    fc = flame_ref.FlameConstants.from_model(flame_model)
+    pt = torch.from_numpy(p.copy())
+    v_ref = flame_ref.vertices_3d(fc, pt, consts=consts)
+    p_ref = flame_ref.reprojected_vertices(fc, pt, to_2d=False, consts=consts)
+    out = hm2.decode(torch.from_numpy(p).cuda(), to_2d=False, landmarks=False)
+    assert (out["verts3d"].cpu() - v_ref).abs().max() < TOL and (out["proj"].cpu() - p_ref).abs().max() < TOL
+    # smaller shape/expression widths pad with zeros (flame.py:192-200)
+    consts3 = {"shape": 100, "expression": 50, "jaw": 3, "rotation": 6, "eyeballs": 0, "neck": 0, "translation": 3, "scale": 1}
+    hm3 = HeadMesh(flame_config=consts3, flame_model=flame_model, static=static, device=0)
+    p3 = np.concatenate([base[:, :100], base[:, 300:350], base[:, 400:]], axis=1)
+    v_ref3 = flame_ref.vertices_3d(fc, torch.from_numpy(p3.copy()), consts=consts3)
+    assert (hm3.vertices_3d(torch.from_numpy(p3)) - v_ref3).abs().max() < TOL
+
+
+def test_duplicate_landmarks_and_565_list(flame_model, static):
+    idx = np.array([5, 5, 0, 5022, 5, 17], dtype=np.int64)
+    hm2 = HeadMesh(flame_model=flame_model, landmarks=idx, static=static, device=0)
+    out = hm2.decode(torch.from_numpy(synthetic.synthetic_params(3, seed=2)).cuda(), landmarks_px=True)
+    assert torch.equal(out["lmk_xy"], out["proj"][:, torch.from_numpy(idx).cuda()])
+    hm2.set_landmarks(landmarks.canonical("565", static))
+    out = hm2.decode(torch.from_numpy(synthetic.synthetic_params(3, seed=2)).cuda())
+    assert out["lmk_xy"].shape == (3, 565, 2)
+    assert torch.equal(out["lmk_xy"], out["proj"][:, torch.from_numpy(landmarks.canonical("565", static)).cuda()])
+    with pytest.raises(_lib.Dad3dError):
+        hm2.set_landmarks([5023])
+
+
+def test_c_abi_host_entry_and_errors(hm, flame_consts):
+    lib = _lib.load()
+    params = synthetic.synthetic_params(3, seed=31)
+    v = np.empty((3, 5023, 3), np.float32)
+    pr = np.empty((3, 5023, 2), np.float32)
+    work = params.copy()
+    _lib.check(lib.dad3d_flame_decode_host(hm.flame._handle, work.ctypes.data, 3, _lib.TO_2D | _lib.MUTATE_PARAMS,
+                                           v.ctypes.data, pr.ctypes.data, None, None))
+    v_ref, p_ref, after = oracle_outputs(flame_consts, params)
+    assert np.abs(v - v_ref).max() < TOL and np.abs(pr - p_ref).max() < TOL and np.array_equal(work, after)
+    # empty batch is a no-op; FLIP_Z with TO_2D is rejected; readjust matches predictor.py:154-176
+    assert lib.dad3d_flame_decode(hm.flame._handle, None, 0, 0, None, None, None, None, None) == _lib.OK
+    assert lib.dad3d_flame_decode_host(hm.flame._handle, work.ctypes.data, 1, _lib.TO_2D | _lib.FLIP_Z, None, None, None, None) == _lib.E_INVALID
+    dev = torch.from_numpy(params.copy()).cuda()
+    _lib.check(lib.dad3d_flame_readjust_params(hm.flame._handle, dev.data_ptr(), 3, None, 25.0, 0.0, 256 / 954, None))
+    torch.cuda.synchronize()
+    ref = flame_ref.readjust_3dmm(torch.from_numpy(params.copy()), [0, 0, 25, 25], 256 / 954)
+    assert (dev.cpu() - ref).abs().max() < 1e-5
+    assert lib.dad3d_flame_num_params(hm.flame._handle) == 413 and lib.dad3d_flame_num_verts(hm.flame._handle) == 5023
+    assert lib.dad3d_flame_num_landmarks(hm.flame._handle) == 445

@@ -1,0 +1,91 @@
+"""CPU: host-side mirrors of the reference interface that need no GPU."""
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from dad_3dheads_amd import flame, landmarks, synthetic
+from oracle import flame_ref
+
+
+def test_from_3dmm_views_and_order():
+    p = torch.arange(2 * 413, dtype=torch.float32).reshape(2, 413)
+    consts = {"shape": 300, "expression": 100, "jaw": 3, "rotation": 6, "eyeballs": 0, "neck": 0, "translation": 3, "scale": 1}
+    fp = flame.FlameParams.from_3dmm(p, consts)
+    assert fp.shape.shape == (2, 300) and fp.expression.shape == (2, 100) and fp.jaw.shape == (2, 3)
+    assert fp.rotation.shape == (2, 6) and fp.eyeballs.shape == (2, 0) and fp.neck.shape == (2, 0)
+    assert fp.jaw[0, 0] == 400 and fp.rotation[0, 0] == 403 and fp.translation[0, 0] == 409 and fp.scale[0, 0] == 412
+    fp.translation[..., 2] = -1.0  # views alias the parent like in the reference
+    assert (p[:, 411] == -1).all()
+    ref = flame_ref.split_3dmm(p, consts)
+    for k in ref:
+        assert torch.equal(getattr(fp, k), ref[k])
+    with pytest.raises(AssertionError):
+        flame.FlameParams.from_3dmm(p[0], consts)
+    # to_3dmm_tensor is bug-compatible: rotation before jaw (flame.py:86-101)
+    t = fp.to_3dmm_tensor()
+    assert torch.equal(t[:, 400:406], p[:, 403:409]) and torch.equal(t[:, 406:409], p[:, 400:403])
+    assert torch.equal(flame.FlameParams.from_3dmm(p, consts, zero_expr=True).expression, torch.zeros(2, 100))
+
+
+def test_canonical_landmark_lists(static):
+    assert np.array_equal(landmarks.canonical("445", static), static["lmk_445"])
+    assert len(landmarks.canonical("565", static)) == 565 and len(landmarks.canonical(191, static)) == 191
+    with pytest.raises(ValueError):
+        landmarks.canonical("68", static)
+
+
+def test_load_indices_from_npy_semantics(tmp_path):
+    d = tmp_path / "kp"
+    d.mkdir()
+    np.save(d / "b.npy", {"x": np.array([5, 6]), "y": np.array([7])}, allow_pickle=True)
+    np.save(d / "a.npy", {"q": np.array([1, 2])}, allow_pickle=True)
+    np.save(d / "cheeks.npy", {"c": np.array([9])}, allow_pickle=True)
+    assert landmarks.load_indices_from_npy(str(d / "b.npy")) == [5, 6, 7]
+    cfg = {"2d_subset_name": "keypoints", "2d_subset_path": str(d)}
+    assert landmarks.load_2d_indices(cfg) == [1, 2, 5, 6, 7]  # sorted files, cheeks excluded
+    cfg["2d_keys_exclude"] = None
+    assert landmarks.load_2d_indices(cfg) == [1, 2, 5, 6, 7, 9]
+    assert landmarks.load_2d_indices({"2d_subset_name": "multipie_keypoints"}) is None
+
+
+def test_synthetic_model_shapes(flame_model):
+    m = flame_model
+    assert m.v_template.shape == (5023, 3) and m.shapedirs.shape == (5023, 3, 400) and m.posedirs.shape == (5023, 3, 36)
+    assert m.J_regressor.shape == (5, 5023) and m.weights.shape == (5023, 5) and m.f.shape == (9976, 3)
+    assert np.allclose(m.J_regressor.sum(1), 1) and np.allclose(m.weights.sum(1), 1)
+    assert m.kintree_table[0].tolist() == [4294967295, 0, 1, 1, 1]
+    p = synthetic.synthetic_params(8, seed=3)
+    assert p.shape == (8, 413) and p.dtype == np.float32 and np.abs(p[:, :400]).max() <= 3.0
+    assert np.array_equal(p, synthetic.synthetic_params(8, seed=3))
+
+
+def test_flame_pickle_loader_without_chumpy(tmp_path, flame_model):
+    # build a pickle whose shapedirs is an instance of a class from a module that will not exist at load time
+    mod = types.ModuleType("chumpy_fake")
+
+    class Ch:
+        def __init__(self, x):
+            self.x = x
+
+    Ch.__module__ = "chumpy_fake"
+    Ch.__qualname__ = "Ch"
+    mod.Ch = Ch
+    sys.modules["chumpy_fake"] = mod
+    import scipy.sparse as sp
+
+    small = dict(f=flame_model.f[:4], v_template=flame_model.v_template[:7], shapedirs=Ch(flame_model.shapedirs[:7]),
+                 posedirs=flame_model.posedirs[:7], J_regressor=sp.csc_matrix(flame_model.J_regressor[:, :7]),
+                 kintree_table=flame_model.kintree_table, weights=flame_model.weights[:7], extra="ignored")
+    path = tmp_path / "flame.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(small, f, protocol=2)
+    del sys.modules["chumpy_fake"]
+    m = flame.get_flame_model(str(path))
+    assert np.array_equal(m.shapedirs, flame_model.shapedirs[:7])
+    assert np.array_equal(m.J_regressor, flame_model.J_regressor[:, :7])
+    with pytest.raises(FileNotFoundError, match="flame.pkl"):
+        flame.get_flame_model(str(tmp_path / "nope.pkl"))
