@@ -42,31 +42,41 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(model, lmk_idx, budget_s: float = 12.0):
+def cpu_baseline(model, lmk_idx, budget_s: float = 15.0):
     """Reference CPU path, timed on this host: per image (B=1) readjust + vertices_3d + reprojected_vertices
     + astype(int) landmark gather, exactly the call sequence of predictor.py:125-145 / demo_utils.py:37-47,
-    through the torch-CPU oracle (the reference's own arithmetic library), all host threads."""
+    through the torch-CPU oracle (the reference's own arithmetic library). The reference never sets a
+    thread count; on a many-core host torch's default (= all cores) is pathologically slow for these small
+    ops, so a few thread counts are tried inside the time budget and the FASTEST is reported (`cores` = the
+    threads it used) -- the most generous reading of the baseline."""
     from oracle import flame_ref
 
     consts = flame_ref.FlameConstants.from_model(model)
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
     params = torch.from_numpy(synthetic.synthetic_params(256, seed=4242))
+    tried = {}
+    candidates = [t for t in (1, 8, 32) if t <= ncpu] or [1]
     with torch.no_grad():
-        for i in range(8):  # warm-up
-            flame_ref.predictor_postprocess(consts, params[i : i + 1].clone(), lmk_idx)
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s:
-            flame_ref.predictor_postprocess(consts, params[n % 256 : n % 256 + 1].clone(), lmk_idx)
-            n += 1
-        dt = time.perf_counter() - t0
+        for threads in candidates:
+            torch.set_num_threads(threads)
+            for i in range(5):  # warm-up
+                flame_ref.predictor_postprocess(consts, params[i : i + 1].clone(), lmk_idx)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s / len(candidates):
+                flame_ref.predictor_postprocess(consts, params[n % 256 : n % 256 + 1].clone(), lmk_idx)
+                n += 1
+            tried[threads] = (n, time.perf_counter() - t0)
+    best = max(tried, key=lambda t: tried[t][0] / tried[t][1])
+    n, dt = tried[best]
     return {
         "value": n / dt,
         "unit": "images/sec",
-        "cores": threads,
+        "cores": best,
         "kind": "port",
-        "sample": f"{n} images, one per call (B=1) like predictor.py: 2 FLAME decodes + 445-landmark int gather each, "
-                  f"torch {torch.__version__} CPU fp32 oracle/flame_ref.py, {dt:.1f} s",
+        "sample": f"{n} images in {dt:.1f} s, one per call (B=1) like predictor.py: readjust + 2 FLAME decodes + "
+                  f"445-landmark int gather each; torch {torch.__version__} CPU fp32 (oracle/flame_ref.py); host has "
+                  f"{ncpu} logical cores; img/s by torch threads: "
+                  + ", ".join(f"{t}: {tried[t][0] / tried[t][1]:.0f}" for t in tried),
     }
 
 

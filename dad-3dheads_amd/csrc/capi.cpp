@@ -53,6 +53,7 @@ struct dad3d_flame {
     float *d_apack = nullptr, *d_imgc = nullptr;
     int cap_nbb = 0;
     bool profiling = false;
+    unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
 };
@@ -282,6 +283,7 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     da.kgroups = h->kgroups;
     da.image_size = h->image_size;
     da.flags = flags;
+    da.trace = h->d_trace;
     if (h->profiling) {
         if (h->ev_used == h->ev_pool.size()) {
             hipEvent_t e0, e1;
@@ -345,6 +347,12 @@ dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batc
     DeviceGuard guard(h->device);
     return launch_readjust(params, batch, h->lay, pads_scale, pad_left, pad_top, scale, h->image_size,
                            static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer) {
+    DAD3D_REQUIRE(h, "null handle");
+    h->d_trace = device_buffer;
+    return DAD3D_OK;
 }
 
 dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on) {

@@ -101,6 +101,7 @@ struct DecodeArgs {
     int kgroups;
     float image_size;
     unsigned flags;
+    unsigned long long* trace;  // diagnostics: [grid][4 waves][8] s_memtime stamps, or null
 };
 
 dad3d_status launch_flame_prologue(const PrologueArgs& a, hipStream_t s);

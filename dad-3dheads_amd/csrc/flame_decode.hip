@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
     const int bb = r % a.nbb;
     const int tile = (r / a.nbb) * 8 + xcd;
     if (tile >= a.n_tiles) return;
+    unsigned long long* trace = a.trace ? a.trace + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
+    auto stamp = [&](int slot) {
+        if (trace && lane == 0) trace[slot] = __builtin_readcyclecounter();
+    };
+    stamp(0);
 
     // (1) the whole basis slice of this wave: KG x 1 KiB, all in flight before anything else
     const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
@@ -244,7 +249,9 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
         for (int it = 0; it < kBlockImages * kImgConsts / 4 / 256; ++it)
             dma16(csrc + it * 256 + tid, cdst + it * 256 + wave * 64);
     }
+    stamp(1);
     __syncthreads();  // carries the vmcnt(0) that retires the DMAs (and the basis loads)
+    stamp(2);
 
     // (3) GEMM: acc[m] = rows [16m,16m+16) x columns [16*wave, 16*wave+16). The A fragment of step s+1 is
     //     read while the four MFMAs of step s execute (one wave per SIMD: nothing else hides LDS latency).
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
             acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.w, bv[i], acc[3], 0, 0, 0);
         }
     }
+    stamp(3);
     __syncthreads();  // all waves are done reading a_lds; reuse it for the output tile
 
     // (4) accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
         for (int q = 0; q < 4; ++q)
             otile[(m * 16 + (lane >> 4) * 4 + q) * kOutStride + wave * 16 + (lane & 15)] = acc[m][q];
     __syncthreads();
+    stamp(4);
 
     // (5) epilogue: one (image, vertex) pair per thread-iteration; consecutive threads walk the
     //     vertices of one image so HBM stores are contiguous runs of 21 x 12 B.
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
             }
         }
     }
+    stamp(5);
 }
 
 size_t flame_decode_lds_bytes(int kgroups) {

@@ -11,7 +11,13 @@ from dad_3dheads_amd.head_mesh import HeadMesh
 from oracle import flame_ref
 
 pytestmark = pytest.mark.gpu
+# north_star: "vertex coords within 1e-4 abs fp32" -- FLAME model units (metres); measured ~3e-7.
 TOL = 1e-4
+TOL_V = 5e-6  # what we actually hold the 3-D vertices to
+# Projected coordinates are pixels = (v*s + t + 1) * 128 with s ~ 6-8 for a crop-filling head, so 1e-4 in
+# vertex units is ~0.08 px; two fp32 evaluation orders of the same formula differ by a few ulp(256) = 3e-5 px
+# each. We hold pixels to 1e-3 px (~80x tighter than the vertex budget mapped to pixels).
+TOL_PX = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -33,8 +39,8 @@ def test_decode_matches_oracle(hm, flame_consts, static, batch):
     dev = torch.from_numpy(params).cuda()
     out = hm.decode(dev, to_2d=False, landmarks=True, landmarks_px=True)
     torch.cuda.synchronize()
-    assert np.abs(out["verts3d"].cpu().numpy() - v_ref).max() < TOL
-    assert np.abs(out["proj"].cpu().numpy() - p_ref).max() < TOL
+    assert np.abs(out["verts3d"].cpu().numpy() - v_ref).max() < TOL_V
+    assert np.abs(out["proj"].cpu().numpy() - p_ref).max() < TOL_PX
     assert np.array_equal(dev.cpu().numpy(), after)  # tz := 0 written back, nothing else touched
     # landmark gather is an exact gather of the projection (index list bit-exact)
     lmk = torch.from_numpy(landmarks.canonical("445", static)).cuda()
@@ -44,7 +50,7 @@ def test_decode_matches_oracle(hm, flame_consts, static, batch):
     ref_px = np.take(p_ref[..., :2].astype(int), landmarks.canonical("445", static), axis=1)
     diff = out["lmk_px"].cpu().numpy() - ref_px
     ref_xy = p_ref[:, landmarks.canonical("445", static), :2]
-    near_int = np.abs(ref_xy - np.round(ref_xy)) < 2 * TOL
+    near_int = np.abs(ref_xy - np.round(ref_xy)) < 2 * TOL_PX
     assert np.all((diff == 0) | ((np.abs(diff) == 1) & near_int))
 
 
@@ -54,9 +60,9 @@ def test_decode_matches_reference_goldens(hm, decode_golden, static):
     out = hm.decode(dev, to_2d=False)
     zero = hm.decode(dev, proj=False, landmarks=False, zero_rotation=True)["verts3d"]
     torch.cuda.synchronize()
-    assert np.abs(out["verts3d"].cpu().numpy() - g["b2_v3d"]).max() < TOL
-    assert np.abs(zero.cpu().numpy() - g["b2_v3d_zero_rot"]).max() < TOL
-    assert np.abs(out["proj"].cpu().numpy() - g["b2_proj3"]).max() < TOL
+    assert np.abs(out["verts3d"].cpu().numpy() - g["b2_v3d"]).max() < TOL_V
+    assert np.abs(zero.cpu().numpy() - g["b2_v3d_zero_rot"]).max() < TOL_V
+    assert np.abs(out["proj"].cpu().numpy() - g["b2_proj3"]).max() < TOL_PX
     assert np.array_equal(dev.cpu().numpy(), g["b2_params_after"])
 
     dev = torch.from_numpy(g["b64_params"].copy()).cuda()
@@ -64,11 +70,11 @@ def test_decode_matches_reference_goldens(hm, decode_golden, static):
     torch.cuda.synchronize()
     sub = g["b64_subset"]
     assert out["proj"].shape == (64, 5023, 2)
-    assert np.abs(out["verts3d"].cpu().numpy()[:, sub] - g["b64_v3d_sub"]).max() < TOL
-    assert np.abs(out["proj"].cpu().numpy()[:, sub] - g["b64_proj_sub"]).max() < TOL
-    assert np.abs(out["lmk_xy"].cpu().numpy() - g["b64_lmk_xy"]).max() < TOL
+    assert np.abs(out["verts3d"].cpu().numpy()[:, sub] - g["b64_v3d_sub"]).max() < TOL_V
+    assert np.abs(out["proj"].cpu().numpy()[:, sub] - g["b64_proj_sub"]).max() < TOL_PX
+    assert np.abs(out["lmk_xy"].cpu().numpy() - g["b64_lmk_xy"]).max() < TOL_PX
     diff = out["lmk_px"].cpu().numpy() - g["b64_lmk_px"]
-    near_int = np.abs(g["b64_lmk_xy"] - np.round(g["b64_lmk_xy"])) < 2 * TOL
+    near_int = np.abs(g["b64_lmk_xy"] - np.round(g["b64_lmk_xy"])) < 2 * TOL_PX
     assert np.all((diff == 0) | ((np.abs(diff) == 1) & near_int))
 
 
@@ -79,11 +85,10 @@ def test_decode_edge_cases_match_goldens(hm, decode_golden):
     zero = hm.decode(dev, proj=False, landmarks=False, zero_rotation=True)["verts3d"]
     torch.cuda.synchronize()
     sub = g["edge_subset"]
-    assert np.abs(out["verts3d"].cpu().numpy()[:, sub] - g["edge_v3d_sub"]).max() < TOL
-    assert np.abs(zero.cpu().numpy()[:, sub] - g["edge_v3d_zero_rot_sub"]).max() < TOL
-    # row 5 has 4x coefficients: coordinates are ~4x larger, so is the fp32 rounding; still inside 1e-4 * scale
+    assert np.abs(out["verts3d"].cpu().numpy()[:, sub] - g["edge_v3d_sub"]).max() < 4 * TOL_V  # row 5: 4x coefficients
+    assert np.abs(zero.cpu().numpy()[:, sub] - g["edge_v3d_zero_rot_sub"]).max() < 4 * TOL_V
     err = np.abs(out["proj"].cpu().numpy()[:, sub] - g["edge_proj3_sub"])
-    assert err[:5].max() < TOL and err[5].max() < 4 * TOL
+    assert err[:5].max() < TOL_PX and err[5].max() < 4 * TOL_PX
     assert np.array_equal(dev.cpu().numpy(), g["edge_params_after"])
     assert torch.all(out["verts3d"][3] == 0) and torch.all(out["verts3d"][4] == 0)  # degenerate 6-DoF -> R = 0
 
@@ -95,19 +100,19 @@ def test_head_mesh_reference_surface(hm, flame_consts):
     v_ref = flame_ref.vertices_3d(flame_consts, ref)
     p_ref = flame_ref.reprojected_vertices(flame_consts, ref, to_2d=True)
     v = hm.vertices_3d(params)
-    assert v.device.type == "cpu" and v.shape == (2, 5023, 3) and (v - v_ref).abs().max() < TOL
+    assert v.device.type == "cpu" and v.shape == (2, 5023, 3) and (v - v_ref).abs().max() < TOL_V
     assert params[0, 411] != 0
     p2 = hm.reprojected_vertices(params_3dmm=params, to_2d=True)
-    assert p2.shape == (2, 5023, 2) and (p2 - p_ref).abs().max() < TOL
+    assert p2.shape == (2, 5023, 2) and (p2 - p_ref).abs().max() < TOL_PX
     assert (params[:, 411] == 0).all() and torch.equal(params, ref)
     assert hm.reprojected_vertices(params, to_2d=False).shape == (2, 5023, 3)
     z = hm.vertices_3d(params, zero_rotation=True)
-    assert (z - flame_ref.vertices_3d(flame_consts, params.clone(), zero_rotation=True)).abs().max() < TOL
+    assert (z - flame_ref.vertices_3d(flame_consts, params.clone(), zero_rotation=True)).abs().max() < TOL_V
     with pytest.raises(AssertionError):
         hm.vertices_3d(params[0])
     # FLAMELayer.forward over FlameParams views (pncc_estimator / losses call style)
     fp = hm.flame_params(params)
-    assert (hm.flame.forward(fp, zero_rot=False) - v_ref).abs().max() < TOL
+    assert (hm.flame.forward(fp, zero_rot=False) - v_ref).abs().max() < TOL_V
     assert hm.flame.faces.shape == (9976, 3) and hm.flame.faces_tensor.dtype == torch.long
     assert hm.flame.indices_2d.shape == (191,)
     adj = hm.adjust_3dmm_to_paddings(params.clone(), [10, 0, 20, 0])
@@ -149,13 +154,13 @@ def test_full_pose_config_neck_and_eyeballs(flame_model, static):
     v_ref = flame_ref.vertices_3d(fc, pt, consts=consts)
     p_ref = flame_ref.reprojected_vertices(fc, pt, to_2d=False, consts=consts)
     out = hm2.decode(torch.from_numpy(p).cuda(), to_2d=False, landmarks=False)
-    assert (out["verts3d"].cpu() - v_ref).abs().max() < TOL and (out["proj"].cpu() - p_ref).abs().max() < TOL
+    assert (out["verts3d"].cpu() - v_ref).abs().max() < TOL_V and (out["proj"].cpu() - p_ref).abs().max() < TOL_PX
     # smaller shape/expression widths pad with zeros (flame.py:192-200)
     consts3 = {"shape": 100, "expression": 50, "jaw": 3, "rotation": 6, "eyeballs": 0, "neck": 0, "translation": 3, "scale": 1}
     hm3 = HeadMesh(flame_config=consts3, flame_model=flame_model, static=static, device=0)
     p3 = np.concatenate([base[:, :100], base[:, 300:350], base[:, 400:]], axis=1)
     v_ref3 = flame_ref.vertices_3d(fc, torch.from_numpy(p3.copy()), consts=consts3)
-    assert (hm3.vertices_3d(torch.from_numpy(p3)) - v_ref3).abs().max() < TOL
+    assert (hm3.vertices_3d(torch.from_numpy(p3)) - v_ref3).abs().max() < TOL_V
 
 
 def test_duplicate_landmarks_and_565_list(flame_model, static):
@@ -180,7 +185,7 @@ def test_c_abi_host_entry_and_errors(hm, flame_consts):
     _lib.check(lib.dad3d_flame_decode_host(hm.flame._handle, work.ctypes.data, 3, _lib.TO_2D | _lib.MUTATE_PARAMS,
                                            v.ctypes.data, pr.ctypes.data, None, None))
     v_ref, p_ref, after = oracle_outputs(flame_consts, params)
-    assert np.abs(v - v_ref).max() < TOL and np.abs(pr - p_ref).max() < TOL and np.array_equal(work, after)
+    assert np.abs(v - v_ref).max() < TOL_V and np.abs(pr - p_ref).max() < TOL_PX and np.array_equal(work, after)
     # empty batch is a no-op; FLIP_Z with TO_2D is rejected; readjust matches predictor.py:154-176
     assert lib.dad3d_flame_decode(hm.flame._handle, None, 0, 0, None, None, None, None, None) == _lib.OK
     assert lib.dad3d_flame_decode_host(hm.flame._handle, work.ctypes.data, 1, _lib.TO_2D | _lib.FLIP_Z, None, None, None, None) == _lib.E_INVALID
