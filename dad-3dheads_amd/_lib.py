@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdad3d_hip.so")
+LIB_PATH = os.environ.get("DAD3D_LIB_PATH") or os.path.join(_HERE, "libdad3d_hip.so")  # override: diagnostics builds
 
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = range(5)
 ZERO_ROTATION, TO_2D, MUTATE_PARAMS, FLIP_Z = 0x1, 0x2, 0x4, 0x8
@@ -75,6 +75,7 @@ SIGNATURES = {
     "dad3d_flame_readjust_params": (_I, [_P, _P, _I, _P, _F, _F, _F, _P]),
     "dad3d_flame_profile_enable": (_I, [_P, _I]),
     "dad3d_flame_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I)]),
+    "dad3d_flame_handoff_timeouts": (_I, [_P, C.POINTER(C.c_uint)]),
     "dad3d_flame_debug_trace": (_I, [_P, _P]),
     "dad3d_mesh_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
     "dad3d_mesh_destroy": (None, [_P]),

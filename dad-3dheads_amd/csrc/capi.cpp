@@ -50,7 +50,9 @@ struct dad3d_flame {
     float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
     int n_lmk = 0;
-    float *d_apack = nullptr, *d_imgc = nullptr;
+    float* d_imgc = nullptr;
+    unsigned* d_sync = nullptr;   // [0] arrival counter, [1] time-out counter
+    unsigned arrive_total = 0;    // host mirror of sync[0] after the last launch
     int cap_nbb = 0;
     bool profiling = false;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
@@ -60,11 +62,9 @@ struct dad3d_flame {
 
 static dad3d_status flame_reserve(dad3d_flame* h, int nbb) {
     if (nbb <= h->cap_nbb) return DAD3D_OK;
-    if (h->d_apack) (void)hipFree(h->d_apack);
     if (h->d_imgc) (void)hipFree(h->d_imgc);
-    h->d_apack = h->d_imgc = nullptr;
+    h->d_imgc = nullptr;
     h->cap_nbb = 0;
-    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_apack), (size_t)nbb * h->ksteps * 256 * sizeof(float)));
     DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_imgc), (size_t)nbb * kBlockImages * kImgConsts * sizeof(float)));
     h->cap_nbb = nbb;
     return DAD3D_OK;
@@ -126,7 +126,7 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
     const bool jaw_only = (c->neck == 0 && c->eyeballs == 0);
     h->n_pose_feats = jaw_only ? 9 : 36;
     h->pose_feat_first = jaw_only ? 9 : 0;
-    const int k_used = 1 + h->n_betas + h->n_pose_feats;  // [template | betas | pose feature]
+    const int k_used = h->n_betas + h->n_pose_feats + 1;  // [betas | pose feature | template]
     h->kgroups = (k_used + 15) / 16;
     h->ksteps = h->kgroups * 4;
     DAD3D_REQUIRE(h->kgroups == 26 || h->kgroups == 28, "unexpected basis depth %d", k_used);
@@ -134,12 +134,16 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
     h->n_tiles = (V + kTileVerts - 1) / kTileVerts;
     h->n_tiles_pad8 = (h->n_tiles + 7) / 8 * 8;
 
-    // ---- pack the basis in MFMA B-fragment order: [tile][kgroup][wave][lane][4 k-steps] ----------
+    // ---- pack the basis in MFMA B-fragment order: [tile][group of 16 k][wave][lane][4 MFMA steps] -------
+    // MFMA step s of group G: lane (q = lane>>4, n = lane&15) supplies basis row k = 16G + 4q + s (the k
+    // order inside a group is permuted so the A operand can be read row-major with one 16-byte LDS load).
     auto basis = [&](int k, int v, int comp) -> float {
-        if (k == 0) return m->v_template[(size_t)v * 3 + comp];
-        if (k <= NB) return m->shapedirs[((size_t)v * 3 + comp) * NB + (k - 1)];
-        const int f = h->pose_feat_first + (k - 1 - NB);
-        return m->posedirs[(size_t)f * 3 * V + (size_t)v * 3 + comp];
+        if (k < NB) return m->shapedirs[((size_t)v * 3 + comp) * NB + k];
+        if (k < NB + h->n_pose_feats) {
+            const int f = h->pose_feat_first + (k - NB);
+            return m->posedirs[(size_t)f * 3 * V + (size_t)v * 3 + comp];
+        }
+        return m->v_template[(size_t)v * 3 + comp];  // k == NB + n_pose_feats: the row multiplied by 1
     };
     std::vector<float> bpack((size_t)h->n_tiles * h->kgroups * 4 * 64 * 4, 0.0f);
     for (int t = 0; t < h->n_tiles; ++t)
@@ -151,7 +155,7 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
                     if (col >= kTileVerts * 3 || v >= V) continue;
                     float* dst = &bpack[((((size_t)t * h->kgroups + g) * 4 + w) * 64 + lane) * 4];
                     for (int i = 0; i < 4; ++i) {
-                        const int k = (g * 4 + i) * 4 + (lane >> 4);
+                        const int k = 16 * g + 4 * (lane >> 4) + i;
                         if (k < k_used) dst[i] = basis(k, v, comp);
                     }
                 }
@@ -177,14 +181,18 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
         }
     }
     std::vector<float> w8((size_t)V * 8, 0.0f);
-    for (int v = 0; v < V; ++v)
-        for (int j = 0; j < kNumJoints; ++j) w8[(size_t)v * 8 + j] = m->lbs_weights[(size_t)v * kNumJoints + j];
+    for (int v = 0; v < V; ++v) {
+        const float* w = &m->lbs_weights[(size_t)v * kNumJoints];
+        for (int j = 0; j < kNumJoints; ++j) w8[(size_t)v * 8 + j] = w[j];
+        w8[(size_t)v * 8 + 5] = ((w[0] + w[1]) + w[3]) + w[4];  // weight of the joints that cannot rotate (jaw-only mode)
+    }
     std::vector<int> head(V, -1);
 
     dad3d_status st;
     if ((st = upload(&h->d_bpack, bpack)) || (st = upload(&h->d_jdirs, jdirs)) || (st = upload(&h->d_j0, j0)) ||
         (st = upload(&h->d_w8, w8)) || (st = upload(&h->d_lmk_head, head)) ||
-        (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = flame_reserve(h.get(), 1))) {
+        (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = upload(&h->d_sync, std::vector<unsigned>(4, 0u))) ||
+        (st = flame_reserve(h.get(), 1))) {
         dad3d_flame_destroy(h.release());
         return st;
     }
@@ -196,7 +204,7 @@ void dad3d_flame_destroy(dad3d_flame* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     for (void* p : {(void*)h->d_bpack, (void*)h->d_jdirs, (void*)h->d_j0, (void*)h->d_w8, (void*)h->d_lmk_head,
-                    (void*)h->d_lmk_next, (void*)h->d_apack, (void*)h->d_imgc})
+                    (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev_pool) {
         (void)hipEventDestroy(e.first);
@@ -245,45 +253,40 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
         dad3d_status st = flame_reserve(h, nbb);
         if (st) return st;
     }
-    PrologueArgs pa{};
-    pa.params = params;
-    pa.jdirs = h->d_jdirs;
-    pa.j0 = h->d_j0;
-    pa.apack = h->d_apack;
-    pa.imgc = h->d_imgc;
-    pa.lay = h->lay;
-    std::copy(h->parents, h->parents + kNumJoints, pa.parents);
-    pa.batch = batch;
-    pa.n_betas = h->n_betas;
-    pa.max_shape = h->max_shape;
-    pa.n_pose_feats = h->n_pose_feats;
-    pa.pose_feat_first = h->pose_feat_first;
-    pa.ksteps = h->ksteps;
-    pa.flags = flags;
-    dad3d_status st = launch_flame_prologue(pa, s);
-    if (st) return st;
-
     DecodeArgs da{};
+    da.params = params;
     da.bpack = h->d_bpack;
-    da.apack = h->d_apack;
-    da.imgc = h->d_imgc;
+    da.jdirs = h->d_jdirs;
+    da.j0 = h->d_j0;
     da.weights8 = h->d_w8;
     da.lmk_head = h->d_lmk_head;
     da.lmk_next = h->d_lmk_next;
+    da.imgc = h->d_imgc;
+    da.sync = h->d_sync;
     da.verts3d = verts3d;
     da.proj = proj;
     da.lmk_xy = lmk_xy;
     da.lmk_px = lmk_px;
+    da.trace = h->d_trace;
+    da.lay = h->lay;
+    std::copy(h->parents, h->parents + kNumJoints, da.parents);
     da.batch = batch;
     da.nbb = nbb;
     da.n_tiles = h->n_tiles;
     da.n_tiles_pad8 = h->n_tiles_pad8;
     da.n_verts = h->n_verts;
     da.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
+    da.n_pose_blocks = (batch + 3) / 4;  // one wave per image, four per workgroup
+    da.n_pose_blocks_pad8 = (da.n_pose_blocks + 7) / 8 * 8;
+    da.n_betas = h->n_betas;
+    da.max_shape = h->max_shape;
+    da.betas_contiguous = (h->lay.shape_n == 300 && h->lay.expr_n == 100 && h->lay.shape_off == 0 && h->lay.expr_off == 300);
     da.kgroups = h->kgroups;
+    da.arrive_target = h->arrive_total + (unsigned)batch;  // every image's pose wave arrives once per launch
+    da.spin_limit = 1u << 20;
     da.image_size = h->image_size;
     da.flags = flags;
-    da.trace = h->d_trace;
+    dad3d_status st;
     if (h->profiling) {
         if (h->ev_used == h->ev_pool.size()) {
             hipEvent_t e0, e1;
@@ -295,6 +298,7 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     }
     st = launch_flame_decode(da, s);
     if (st) return st;
+    h->arrive_total = da.arrive_target;  // committed only once the launch was accepted
     if (h->profiling) {
         DAD3D_HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].second, s));
         ++h->ev_used;
@@ -347,6 +351,14 @@ dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batc
     DeviceGuard guard(h->device);
     return launch_readjust(params, batch, h->lay, pads_scale, pad_left, pad_top, scale, h->image_size,
                            static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count) {
+    DAD3D_REQUIRE(h && count, "null argument");
+    DeviceGuard guard(h->device);
+    DAD3D_HIP_TRY(hipDeviceSynchronize());
+    DAD3D_HIP_TRY(hipMemcpy(count, h->d_sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return DAD3D_OK;
 }
 
 dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer) {

@@ -52,7 +52,7 @@ struct DeviceGuard {
 constexpr int kTileVerts = 21;   // vertices per column tile: 63 basis columns + 1 zero pad = 64
 constexpr int kTileCols = 64;    // 4 waves x one 16-wide MFMA column block
 constexpr int kBlockImages = 64; // images (GEMM rows) per workgroup: 4 MFMA row blocks of 16
-constexpr int kImgConsts = 80;   // floats per image in the per-image constant block
+constexpr int kImgConsts = 84;   // floats per image: A_j 5x12 (jaw first) | R 9 | s tx ty | 4 compact translations
 constexpr int kNumJoints = 5;    // FLAME: global, neck, jaw, left eye, right eye
 constexpr int kOutStride = 68;   // LDS row stride of the accumulator tile (conflict-free ds_write_b32)
 
@@ -69,42 +69,34 @@ struct ParamLayout {
     int scale_off;
 };
 
-struct PrologueArgs {
-    float* params;          // [B,P]
+struct DecodeArgs {
+    float* params;          // [B,P] (tz written when DAD3D_MUTATE_PARAMS)
+    const float* bpack;     // [n_tiles][kgroups][4 waves][64 lanes][4]: basis in MFMA B-fragment order
     const float* jdirs;     // [15][n_betas]  J_regressor . shapedirs
     const float* j0;        // [15]           J_regressor . v_template
-    float* apack;           // [nbb][ksteps][64 lanes][4 row blocks]
-    float* imgc;            // [nbb*64][kImgConsts]
+    const float* weights8;  // [V][8] skinning weights w0..w4, S = w0+w1+w3+w4, 0, 0
+    const int* lmk_head;    // [V] first landmark slot of a vertex or -1
+    const int* lmk_next;    // [n_lmk] next slot with the same vertex or -1
+    float* imgc;            // [B][kImgConsts] per-image constants: pose role -> decode role hand-off
+    unsigned* sync;         // [0] arrivals (monotonic over launches)  [1] hand-off time-outs (sticky)
+    float* verts3d;         // [B,V,3] or null
+    float* proj;            // [B,V,2|3] or null
+    float* lmk_xy;          // [B,n_lmk,2] or null
+    int32_t* lmk_px;        // [B,n_lmk,2] or null
+    unsigned long long* trace;  // diagnostics: [decode blocks][4 waves][32] s_memtime stamps, or null
     ParamLayout lay;
     int parents[kNumJoints];
-    int batch;
-    int n_betas;   // 400
-    int max_shape; // 300
-    int n_pose_feats; // 9 (jaw only) or 36
-    int pose_feat_first; // 9 or 0
-    int ksteps;    // K/4, multiple of 4
-    unsigned flags;
-};
-
-struct DecodeArgs {
-    const float* bpack;    // [n_tiles][kgroups][4 waves][64 lanes][4]
-    const float* apack;
-    const float* imgc;
-    const float* weights8; // [V][8] skinning weights, zero padded
-    const int* lmk_head;   // [V] first landmark slot of a vertex or -1
-    const int* lmk_next;   // [n_lmk] next slot with the same vertex or -1
-    float* verts3d;        // [B,V,3] or null
-    float* proj;           // [B,V,2|3] or null
-    float* lmk_xy;         // [B,n_lmk,2] or null
-    int32_t* lmk_px;       // [B,n_lmk,2] or null
     int batch, nbb, n_tiles, n_tiles_pad8, n_verts, n_lmk;
+    int n_pose_blocks, n_pose_blocks_pad8;
+    int n_betas, max_shape;  // 400, 300
+    int betas_contiguous;    // params[0:400] are the betas (shape == 300 and expression == 100)
     int kgroups;
+    unsigned arrive_target;  // value of sync[0] once every image of this launch has been published
+    unsigned spin_limit;
     float image_size;
     unsigned flags;
-    unsigned long long* trace;  // diagnostics: [grid][4 waves][8] s_memtime stamps, or null
 };
 
-dad3d_status launch_flame_prologue(const PrologueArgs& a, hipStream_t s);
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s);
 dad3d_status launch_readjust(float* params, int batch, ParamLayout lay, const float* pads_scale, float pad_left,
                              float pad_top, float scale, float img_size, hipStream_t s);

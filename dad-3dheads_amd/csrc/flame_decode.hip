@@ -1,34 +1,48 @@
-// FLAME / HeadMesh decode for gfx950 (MI355X): two kernels per batch.
+// FLAME / HeadMesh decode for gfx950 (MI355X): ONE launch per batch, two workgroup roles.
 //
-//   flame_prologue_kernel  (one wave per image, tiny)
-//       params row -> betas, joints J = J0 + Jdirs.betas, Rodrigues per joint, pose feature,
-//       kinematic chain A_j, 6-DoF rotation R, scale/translation  ->  per-image constant block
-//       + the image's row of the packed GEMM A operand.
-//       Restates FLAMELayer.forward's setup (model_training/model/flame.py:191-210), the smplx.lbs
-//       steps 2,3,5 and rot_mat_from_6dof (model_training/model/utils.py:92-101).
+//   pose role   (the first ceil(B/4) workgroups, one 64-lane wave per image)
+//       params row -> joints J = J0 + Jdirs.betas, Rodrigues per joint, kinematic chain A_j, 6-DoF rotation R,
+//       scale/translation -> an 84-float per-image constant block, published write-through (sc1) to HBM,
+//       then one agent-scope arrival per image on a monotonic counter.
+//       Restates FLAMELayer.forward's setup (model_training/model/flame.py:191-210), smplx.lbs steps 2,3,5
+//        and rot_mat_from_6dof (model_training/model/utils.py:92-101).
 //
-//   flame_decode_kernel<KG>  (the dominant kernel)
-//       v_posed[B, 3V] = [1 | betas | pose_feature] . [v_template ; shapedirs ; posedirs]   on fp32 MFMA
-//       (v_mfma_f32_16x16x4_f32: exact fp32 fma chains, so results track the fp32 reference to ~1e-7),
-//       then in the same kernel: linear-blend skinning, +MESH_OFFSET_Z, 6-DoF rotation,
-//       scale/translate, NDC->pixel map, landmark gather  (smplx.lbs steps 1,4,6; flame.py:224-228;
-//       model_training/head_mesh.py:39-45; demo_utils.py:42-46).
+//   decode role (one workgroup per 64 images x 21 vertices)
+//       v_posed[B, 3V] = [betas | pose_feature | 1] . [shapedirs ; posedirs ; v_template]   on fp32 MFMA
+//       (v_mfma_f32_16x16x4_f32: exact fp32 fma chains -> tracks the fp32 reference to ~1e-7), then, in the
+//       same workgroup: linear-blend skinning, +MESH_OFFSET_Z, 6-DoF rotation, scale/translate, NDC->pixel
+//       map, landmark gather (smplx.lbs steps 1,4,6; flame.py:224-228; model_training/head_mesh.py:39-45;
+//       demo_utils.py:42-46). The GEMM needs nothing from the pose role (betas come straight from the
+//       params rows, the pose feature is one Rodrigues per image), so both roles run CONCURRENTLY; only the
+//       epilogue consumes the pose role's block, after one relaxed poll of the arrival counter. The
+//       hand-off is placement independent (sc1 stores, drained, relaxed agent-scope counter; consumer reads
+//       with sc1 loads) and every spin is bounded: on time-out a decode workgroup computes the constants of
+//       its own 64 images itself.
 //
-// Work decomposition: a workgroup owns 64 images x 21 vertices (63 basis columns + 1 pad).
-// 5023 vertices -> 240 tiles -> one workgroup per CU on 240 of the 256 CUs, one wave per SIMD, and every
-// wave issues exactly 4 x 104 MFMAs: wave w owns column block w (16 columns) for all four 16-image row
-// blocks. The basis tile of a wave (26 KB for K=416) is requested with 26 x 1 KiB loads up front; the A
-// operand (shared by the four waves) is staged once in LDS in lane-linear order so that one conflict-free
-// ds_read_b128 feeds four MFMAs.
+// Work decomposition: 5023 vertices -> 240 column tiles of 21 vertices (63 basis columns + 1
+// pad) -> 240 decode workgroups on 240 of the 256 CUs (the pose role's 16 workgroups take the rest), one
+// wave per SIMD, every wave issues exactly 4 x 104 MFMAs: wave w owns column block w (16 columns) for all
+// four 16-image row blocks. B (basis, 26 KB per wave) streams straight into VGPRs, packed on the host in
+// fragment order; A (64 params rows, shared by the four waves) is register-staged into a row-major LDS
+// image in 32-column chunks that stay 3-4 chunks ahead of the MFMAs. The k order inside every 16-row
+// group is permuted (lane group q takes rows 4q..4q+3) so that one conflict-free ds_read_b128 delivers a
+// lane's A operand for four consecutive MFMAs straight from the row-major image.
 #include "common.hpp"
+
+#ifndef DAD3D_ABLATE  // diagnostics builds only (tools/ablate.sh); 0 in the product
+#define DAD3D_ABLATE 0
+#endif
 
 namespace dad3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B load from a 4-byte aligned row
 
 namespace {
 
 constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
+constexpr int kCacheSc1 = 16;          // buffer-op aux bit: write-through store / L1-bypassing load
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -53,10 +67,9 @@ __device__ __forceinline__ void rodrigues(const float r[3], float R[9]) {
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * K[i] + c1 * KK[i];
 }
 
-// 16-byte LDS-DMA: lane l's global address `src` lands at `lds_wave_base + 16*l` (base is wave-uniform)
-__device__ __forceinline__ void dma16(const float4* src, float4* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+__device__ __forceinline__ void identity3(float R[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
 }
 
 __device__ __forceinline__ void normalize3(float v[3]) {  // F.normalize(eps=1e-12)
@@ -66,42 +79,53 @@ __device__ __forceinline__ void normalize3(float v[3]) {  // F.normalize(eps=1e-
     v[2] /= n;
 }
 
-}  // namespace
+// full_pose = [global 0 | neck | jaw | eyeballs] (flame.py:201-208): the up-to-12 pose inputs of one image
+struct PoseIn {
+    float neck[3], jaw[3], eyes[6];
+};
 
-// -------------------------------------------------------------------------------------------------
-// Prologue: one 64-lane wave per image.
-// -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void flame_prologue_kernel(PrologueArgs a) {
-    __shared__ float sh[kImgConsts + 40];  // [0,80): image constants, [80,116): pose feature
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const bool live = b < a.batch;
-    const int bb = b / kBlockImages, bi = b % kBlockImages;
-    const int rb = bi >> 4, ri = bi & 15;  // MFMA row block / row within block
-    float* arow = a.apack + (size_t)bb * a.ksteps * 256;  // this batch block's operand
-    auto a_store = [&](int k, float v) { arow[((k >> 2) * 64 + (k & 3) * 16 + ri) * 4 + rb] = v; };
-    const int k_pose = 1 + a.n_betas;
-    const int k_end = k_pose + a.n_pose_feats;
-    const int K = a.ksteps * 4;
+__device__ __forceinline__ PoseIn load_pose(const float* p, const ParamLayout& lay) {
+    PoseIn in;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) in.neck[c] = (lay.neck_n == 3) ? p[lay.neck_off + c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) in.jaw[c] = (lay.jaw_n == 3) ? p[lay.jaw_off + c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) in.eyes[c] = (lay.eye_n == 6) ? p[lay.eye_off + c] : 0.0f;
+    return in;
+}
 
-    if (!live) {  // rows of a ragged last block: defined zeros, never stored by the decode kernel
-        for (int k = lane; k < K; k += 64) a_store(k, 0.0f);
-        for (int i = lane; i < kImgConsts; i += 64) a.imgc[(size_t)b * kImgConsts + i] = 0.0f;
-        return;
+// -> per-joint rotation matrices. A joint whose pose input has size 0 gets the exact identity (which is
+// also what Rodrigues returns for a zero vector).
+__device__ __forceinline__ void joint_rotations(const PoseIn& in, const ParamLayout& lay, float R[kNumJoints][9]) {
+    identity3(R[0]);
+    if (lay.neck_n == 3) rodrigues(in.neck, R[1]); else identity3(R[1]);
+    if (lay.jaw_n == 3) rodrigues(in.jaw, R[2]); else identity3(R[2]);
+    if (lay.eye_n == 6) {
+        rodrigues(in.eyes, R[3]);
+        rodrigues(in.eyes + 3, R[4]);
+    } else {
+        identity3(R[3]);
+        identity3(R[4]);
     }
-    float* p = a.params + (size_t)b * a.lay.n_params;
+}
 
-    // betas = [shape | 0.. | expression | 0..]  (flame.py:192-200), and J = J0 + Jdirs . betas
+// betas[l] = [shape | 0.. | expression | 0..][l]  (flame.py:192-200)
+__device__ __forceinline__ float beta_at(const float* p, const DecodeArgs& a, int l) {
+    if (l < a.max_shape) return (l < a.lay.shape_n) ? p[a.lay.shape_off + l] : 0.0f;
+    return (l - a.max_shape < a.lay.expr_n) ? p[a.lay.expr_off + l - a.max_shape] : 0.0f;
+}
+
+// One wave computes the 84-float constant block of one image into `scr` (LDS, wave-private, >= 84 floats):
+//   [0,60)  A_j rows 0..2 of the 4x4 relative transforms, joint order 2,0,1,3,4 (jaw first)
+//   [60,69) R from the 6-DoF vector     [69] s = max(scale+1, 1e-8)   [70,72) tx ty
+//   [72,84) the four non-jaw translations again, compact (jaw-only fast path of the epilogue)
+__device__ void image_constants(const DecodeArgs& a, const float* p, float* scr, int lane) {
     float jacc[3 * kNumJoints];
 #pragma unroll
     for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] = 0.0f;
     for (int l = lane; l < a.n_betas; l += 64) {
-        float beta;
-        if (l < a.max_shape)
-            beta = (l < a.lay.shape_n) ? p[a.lay.shape_off + l] : 0.0f;
-        else
-            beta = (l - a.max_shape < a.lay.expr_n) ? p[a.lay.expr_off + l - a.max_shape] : 0.0f;
-        a_store(1 + l, beta);
+        const float beta = beta_at(p, a, l);
 #pragma unroll
         for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] += a.jdirs[o * a.n_betas + l] * beta;
     }
@@ -109,31 +133,14 @@ __global__ __launch_bounds__(64) void flame_prologue_kernel(PrologueArgs a) {
 #pragma unroll
     for (int o = 0; o < 3 * kNumJoints; ++o) J[o / 3][o % 3] = a.j0[o] + wave_sum(jacc[o]);
 
-    // Everything below is ~600 flops of scalar work: every lane computes it redundantly (uniform
-    // loads), lane 0 publishes through LDS so the stores to HBM are coalesced.
-    // full_pose = [global 0 | neck | jaw | eyeballs]  (flame.py:201-208)
-    float pose[kNumJoints][3];
-#pragma unroll
-    for (int j = 0; j < kNumJoints; ++j) pose[j][0] = pose[j][1] = pose[j][2] = 0.0f;
-    if (a.lay.neck_n == 3)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pose[1][c] = p[a.lay.neck_off + c];
-    if (a.lay.jaw_n == 3)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pose[2][c] = p[a.lay.jaw_off + c];
-    if (a.lay.eye_n == 6)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) pose[3 + c / 3][c % 3] = p[a.lay.eye_off + c];
-
+    // ~600 flops of scalar work: every lane computes it redundantly (uniform loads), lane 0 writes it out
     float R[kNumJoints][9];
-#pragma unroll
-    for (int j = 0; j < kNumJoints; ++j) rodrigues(pose[j], R[j]);
-
+    joint_rotations(load_pose(p, a.lay), a.lay, R);
     // kinematic chain (smplx batch_rigid_transform): world_j = world_parent . [R_j | J_j - J_parent]
     float WR[kNumJoints][9], Wt[kNumJoints][3];
 #pragma unroll
     for (int j = 0; j < kNumJoints; ++j) {
-        if (j == 0 || a.parents[j] < 0) {
+        if (j == 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) WR[j][i] = R[j][i];
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(64) void flame_prologue_kernel(PrologueArgs a) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) Pt[c] = Wt[q][c], Jp[c] = J[q][c];
                 }
-            float rel[3] = {J[j][0] - Jp[0], J[j][1] - Jp[1], J[j][2] - Jp[2]};
+            const float rel[3] = {J[j][0] - Jp[0], J[j][1] - Jp[1], J[j][2] - Jp[2]};
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -159,7 +166,6 @@ __global__ __launch_bounds__(64) void flame_prologue_kernel(PrologueArgs a) {
             }
         }
     }
-
     // 6-DoF -> rotation (model/utils.py:92-101), columns b1 b2 b3
     float b1[3] = {p[a.lay.rot_off], p[a.lay.rot_off + 1], p[a.lay.rot_off + 2]};
     const float vy[3] = {p[a.lay.rot_off + 3], p[a.lay.rot_off + 4], p[a.lay.rot_off + 5]};
@@ -168,159 +174,399 @@ __global__ __launch_bounds__(64) void flame_prologue_kernel(PrologueArgs a) {
     normalize3(b3);
     const float b2[3] = {-(b1[1] * b3[2] - b1[2] * b3[1]), -(b1[2] * b3[0] - b1[0] * b3[2]),
                          -(b1[0] * b3[1] - b1[1] * b3[0])};
-
     if (lane == 0) {
-        // A_j = world_j - [0 | world_j . J_j]  -> rows 0..2 of the 4x4, 12 floats per joint
+        // A_j = world_j - [0 | world_j . J_j]
 #pragma unroll
-        for (int j = 0; j < kNumJoints; ++j)
+        for (int j = 0; j < kNumJoints; ++j) {
+            const int slot = (j == 2) ? 0 : (j < 2 ? j + 1 : j);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) sh[j * 12 + r * 4 + c] = WR[j][r * 3 + c];
-                sh[j * 12 + r * 4 + 3] =
+                for (int c = 0; c < 3; ++c) scr[slot * 12 + r * 4 + c] = WR[j][r * 3 + c];
+                const float t =
                     Wt[j][r] - (WR[j][r * 3] * J[j][0] + WR[j][r * 3 + 1] * J[j][1] + WR[j][r * 3 + 2] * J[j][2]);
+                scr[slot * 12 + r * 4 + 3] = t;
+                if (slot > 0) scr[72 + (slot - 1) * 3 + r] = t;
             }
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            sh[60 + r * 3 + 0] = b1[r];
-            sh[60 + r * 3 + 1] = b2[r];
-            sh[60 + r * 3 + 2] = b3[r];
+            scr[60 + r * 3 + 0] = b1[r];
+            scr[60 + r * 3 + 1] = b2[r];
+            scr[60 + r * 3 + 2] = b3[r];
         }
-        sh[69] = fmaxf(p[a.lay.scale_off] + 1.0f, 1e-8f);  // head_mesh.py:39
-        sh[70] = p[a.lay.trans_off];
-        sh[71] = p[a.lay.trans_off + 1];  // translation z := 0 (head_mesh.py:41)
-#pragma unroll
-        for (int i = 72; i < kImgConsts; ++i) sh[i] = 0.0f;
-        // pose_feature = (R[1:] - I).view(36)
-#pragma unroll
-        for (int j = 1; j < kNumJoints; ++j)
-#pragma unroll
-            for (int i = 0; i < 9; ++i) sh[kImgConsts + (j - 1) * 9 + i] = R[j][i] - ((i % 4 == 0) ? 1.0f : 0.0f);
-        if (a.flags & DAD3D_MUTATE_PARAMS) p[a.lay.trans_off + 2] = 0.0f;
+        scr[69] = fmaxf(p[a.lay.scale_off] + 1.0f, 1e-8f);  // head_mesh.py:39
+        scr[70] = p[a.lay.trans_off];
+        scr[71] = p[a.lay.trans_off + 1];  // translation z := 0 (head_mesh.py:41)
     }
-    __syncthreads();
-    for (int i = lane; i < kImgConsts; i += 64) a.imgc[(size_t)b * kImgConsts + i] = sh[i];
-    if (lane == 0) a_store(0, 1.0f);  // the template row of the basis
-    if (lane < a.n_pose_feats) a_store(k_pose + lane, sh[kImgConsts + a.pose_feat_first + lane]);
-    for (int k = k_end + lane; k < K; k += 64) a_store(k, 0.0f);
 }
 
-// -------------------------------------------------------------------------------------------------
-// Fused blend-shape GEMM + skinning + rotation + projection + landmark gather
-// -------------------------------------------------------------------------------------------------
+// ---- LDS map of the decode role (floats) -------------------------------------------------------------
 template <int KG>
+struct DecodeLds {
+    static constexpr int K = KG * 16;
+    static constexpr int LD = (KG == 26) ? 424 : 456;  // row stride: ds_read_b128 of the A operand conflict-free
+    static constexpr int a_off = 0;                    // [64 images][LD]
+    static constexpr int imgc_off = kBlockImages * LD; // [64][kImgConsts]
+    static constexpr int vc_off = imgc_off + kBlockImages * kImgConsts;  // [21][8] skinning weights
+    static constexpr int lh_off = vc_off + kTileVerts * 8;               // [24] landmark heads (+ hand-off flag)
+    static constexpr int o_off = lh_off + 24;                            // [64][kOutStride] accumulator tile
+    static constexpr int total = o_off + kBlockImages * kOutStride;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// pose role
+// ------------------------------------------------------------------------------------------------------
+__device__ void pose_role(const DecodeArgs& a, float* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= a.batch) return;
+    float* scr = smem + wave * 96;
+    float* p = a.params + (size_t)b * a.lay.n_params;
+    image_constants(a, p, scr, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 0's LDS writes before the other lanes read
+    if (lane == 0 && (a.flags & DAD3D_MUTATE_PARAMS)) p[a.lay.trans_off + 2] = 0.0f;  // head_mesh.py:41
+    // publish: write-through (sc1) 16-byte stores, drained, then ONE relaxed agent-scope arrival
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.imgc + (size_t)b * kImgConsts, 0, kImgConsts * (int)sizeof(float), 0x00020000);
+    if (lane < kImgConsts / 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scr + lane * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, lane * 16, 0, kCacheSc1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// the fused kernel
+// ------------------------------------------------------------------------------------------------------
+// CONTIG: params[:, 0:400] are the betas (shape == 300, expression == 100: the dad_3dnet.yaml constants), so
+// the A operand is copied with 16-byte loads; otherwise it is gathered element by element (flame.py:192-200).
+template <int KG, bool JAW_ONLY, bool CONTIG>
 __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kSteps = KG * 4;                       // MFMA k-steps (4 basis rows each)
-    float4* a_lds = reinterpret_cast<float4*>(smem);     // [kSteps][64 lanes] x {4 row blocks}
-    float* imgc = smem + kSteps * 256;                   // [64][kImgConsts]
-    float* otile = smem;                                 // [64][kOutStride], aliases a_lds after the GEMM
+    if ((int)blockIdx.x < a.n_pose_blocks_pad8) {
+        if ((int)blockIdx.x < a.n_pose_blocks) pose_role(a, smem);
+        return;
+    }
+    using L = DecodeLds<KG>;
+    constexpr int LD = L::LD;
+    constexpr int kChunks = KG / 2;   // staging granule: 32 k = 2 MFMA groups = 8 k-steps
+    constexpr int kAhead = 3;         // staging registers hold 3 chunks (named ring below)
+    constexpr int kNumBeta = 400;     // MAX_SHAPE + MAX_EXPRESSION, checked on the host
+    float* a_lds = smem + L::a_off;
+    float* imgc = smem + L::imgc_off;
+    float* vconst = smem + L::vc_off;
+    int* lmkh = reinterpret_cast<int*>(smem + L::lh_off);
+    float* otile = smem + L::o_off;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware block -> (tile, batch block): blocks land on XCD (id % 8); the batch blocks that share
-    // one basis tile are consecutive on one XCD so the tile is fetched into that L2 once.
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
-    const int bb = r % a.nbb;
-    const int tile = (r / a.nbb) * 8 + xcd;
+    // XCD-aware block -> (tile, batch block): blocks land on XCD (blockIdx % 8); the batch blocks that
+    // share one basis tile are consecutive on one XCD so the tile is fetched into that L2 once.
+    const int gid = (int)blockIdx.x - a.n_pose_blocks_pad8;
+    const int xcd = gid & 7, rr = gid >> 3;
+    const int bb = rr % a.nbb;
+    const int tile = (rr / a.nbb) * 8 + xcd;
     if (tile >= a.n_tiles) return;
-    unsigned long long* trace = a.trace ? a.trace + ((size_t)blockIdx.x * 4 + wave) * 8 : nullptr;
+    unsigned long long* trace = a.trace ? a.trace + ((size_t)gid * 4 + wave) * 32 : nullptr;
     auto stamp = [&](int slot) {
         if (trace && lane == 0) trace[slot] = __builtin_readcyclecounter();
     };
     stamp(0);
+    const int img0 = bb * kBlockImages;
+    const int v0 = tile * kTileVerts;
+    const int P = a.lay.n_params;
 
-    // (1) the whole basis slice of this wave: KG x 1 KiB, all in flight before anything else
+    // ---- operand streams ----------------------------------------------------------------------------
+    // B: wave-private 16 columns, fragment-ordered on the host, 1 KiB per load, straight to VGPRs.
     const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
+    // A: thread copies float4 (row, 4*c4 + 32*chunk) for rows srow and srow+32 of the 64 params rows.
+    const int srow = tid >> 3, c4 = tid & 7;
+    const bool live0 = img0 + srow < a.batch, live1 = img0 + srow + 32 < a.batch;
+    const float* prow0 = a.params + (size_t)(img0 + srow) * P;
+    const float* prow1 = a.params + (size_t)(img0 + srow + 32) * P;
+    float* adst0 = a_lds + srow * LD + 4 * c4;
+    float* adst1 = adst0 + 32 * LD;
+    auto beta4 = [&](const float* prow, bool live, int k) -> float4 {
+        float4 r = {0.f, 0.f, 0.f, 0.f};
+        if (live && k < kNumBeta) {
+            if (CONTIG) {
+                const f4u v = *reinterpret_cast<const f4u*>(prow + k);
+                r = float4{v.x, v.y, v.z, v.w};
+            } else {
+                r = float4{beta_at(prow, a, k), beta_at(prow, a, k + 1), beta_at(prow, a, k + 2), beta_at(prow, a, k + 3)};
+            }
+        }
+        return r;
+    };
     float4 bq[KG];
+    float4 sa0, sb0, sa1, sb1, sa2, sb2;  // staging ring, named (an indexed array ends up in scratch)
+    static_assert(kAhead == 3, "the staging ring below is written out for 3 chunks in flight");
+    // k >= 400 (pose feature, template row, zero padding) is written by the tail code, not staged
+#define DAD3D_ISSUE(c)                                                          \
+    do {                                                                        \
+        bq[2 * (c)] = bsrc[(size_t)(2 * (c)) * 256];                            \
+        bq[2 * (c) + 1] = bsrc[(size_t)(2 * (c) + 1) * 256];                    \
+        if (32 * (c) < kNumBeta) {                                              \
+            const float4 la = beta4(prow0, live0, 32 * (c) + 4 * c4);           \
+            const float4 lb = beta4(prow1, live1, 32 * (c) + 4 * c4);           \
+            if ((c) % 3 == 0) sa0 = la, sb0 = lb;                               \
+            else if ((c) % 3 == 1) sa1 = la, sb1 = lb;                          \
+            else sa2 = la, sb2 = lb;                                            \
+        }                                                                       \
+    } while (0)
+#define DAD3D_COMMIT(c)                                                                            \
+    do {                                                                                           \
+        if (32 * (c) < kNumBeta && 32 * (c) + 4 * c4 < kNumBeta) {                                 \
+            *reinterpret_cast<float4*>(adst0 + 32 * (c)) = (c) % 3 == 0 ? sa0 : (c) % 3 == 1 ? sa1 : sa2; \
+            *reinterpret_cast<float4*>(adst1 + 32 * (c)) = (c) % 3 == 0 ? sb0 : (c) % 3 == 1 ? sb1 : sb2; \
+        }                                                                                          \
+    } while (0)
 #pragma unroll
-    for (int g = 0; g < KG; ++g) bq[g] = bsrc[(size_t)g * 256];
-
-    // (2) A operand + per-image constants of this batch block -> LDS by LDS-DMA (global_load_lds_dwordx4:
-    //     no VGPR round trip; the destination is wave-uniform base + lane*16, i.e. exactly our lane-linear
-    //     images). Every DMA is in flight together with the basis loads above.
-    {
-        const float4* asrc = reinterpret_cast<const float4*>(a.apack) + (size_t)bb * kSteps * 64;
-#pragma unroll
-        for (int it = 0; it < kSteps / 4; ++it)
-            dma16(asrc + it * 256 + tid, a_lds + it * 256 + wave * 64);
-        const float4* csrc = reinterpret_cast<const float4*>(a.imgc + (size_t)bb * kBlockImages * kImgConsts);
-        float4* cdst = reinterpret_cast<float4*>(imgc);
-#pragma unroll
-        for (int it = 0; it < kBlockImages * kImgConsts / 4 / 256; ++it)
-            dma16(csrc + it * 256 + tid, cdst + it * 256 + wave * 64);
+    for (int c = 0; c < kAhead; ++c) DAD3D_ISSUE(c);
+    // pose inputs of image (16*wave + lane) for the A rows past the betas: loaded now, used after chunk 1
+    PoseIn pose_in{};
+    const bool tail_live = lane < 16 && img0 + wave * 16 + lane < a.batch;
+    if (tail_live) pose_in = load_pose(a.params + (size_t)(img0 + wave * 16 + lane) * P, a.lay);
+    // per-vertex constants of the tile: loaded now, parked in LDS mid-GEMM, used by the epilogue
+    float vc = 0.0f;
+    int lh = -1;
+    if (tid < kTileVerts * 8) {
+        const int v = v0 + tid / 8;
+        vc = (v < a.n_verts) ? a.weights8[(size_t)v * 8 + (tid & 7)] : 0.0f;
     }
+    if (tid < kTileVerts && v0 + tid < a.n_verts && a.n_lmk > 0) lh = a.lmk_head[v0 + tid];
+    __builtin_amdgcn_sched_barrier(0);
     stamp(1);
-    __syncthreads();  // carries the vmcnt(0) that retires the DMAs (and the basis loads)
+    DAD3D_COMMIT(0);
+    DAD3D_ISSUE(kAhead);  // reuses chunk 0's staging registers, hence after its commit
+    DAD3D_COMMIT(1);
+    __syncthreads();
     stamp(2);
 
-    // (3) GEMM: acc[m] = rows [16m,16m+16) x columns [16*wave, 16*wave+16). The A fragment of step s+1 is
-    //     read while the four MFMAs of step s execute (one wave per SIMD: nothing else hides LDS latency).
+    // ---- GEMM ---------------------------------------------------------------------------------------
+    // acc[m] = images [16m,16m+16) x columns [16*wave,16*wave+16). MFMA step (G, s): lane group q = lane>>4
+    // contributes basis row k = 16G + 4q + s, so the A operand of lane (q, i) for s = 0..3 is the float4
+    // at a_lds[16m + i][16G + 4q]. The fragments of group G+1 are read while group G multiplies.
+    constexpr int kVec = kBlockImages * kImgConsts / 4;  // float4s of this block's per-image constants
+    constexpr int kCst = (kVec + 255) / 256;
+    const __amdgpu_buffer_rsrc_t imgc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.imgc + (size_t)img0 * kImgConsts, 0, min(kBlockImages, a.batch - img0) * kImgConsts * (int)sizeof(float),
+        0x00020000);  // rows past the batch read as zeros (buffer bounds check)
+    int* handoff_ok = lmkh + 23;
+    unsigned seen_early = 0;
+    bool early = false;
+    u32x4 cst[kCst];
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 av = a_lds[lane];
-    float4 av1 = a_lds[64 + lane];
+    const float* afrag = a_lds + (lane & 15) * LD + 4 * (lane >> 4);
+    float4 af[4], an[4] = {};
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-        const float bv[4] = {bq[g].x, bq[g].y, bq[g].z, bq[g].w};
+    for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
+    // Per chunk (2 groups = 32 MFMAs = 1024 cycles of the matrix pipe): after step 1 the loads of chunk c+4
+    // are issued, after step 3 chunk c+2 goes from the staging registers to LDS -- half a chunk before the
+    // barrier that publishes it, so neither the ds_writes nor their lgkmcnt drain sit on the MFMA path.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = g * 4 + i;
-            const float4 cur = av;
-            av = av1;
-            if (s + 2 < kSteps) av1 = a_lds[(s + 2) * 64 + lane];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x, bv[i], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.y, bv[i], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.z, bv[i], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.w, bv[i], acc[3], 0, 0, 0);
+    for (int c = 0; c < kChunks; ++c) {
+        if (c > 0 && !(DAD3D_ABLATE & 4)) __syncthreads();  // chunk c+1 (written during chunk c-1) is now visible to every wave
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int G = 2 * c + (q >> 2), s = q & 3;
+            if (s == 0 && G + 1 < KG && !(DAD3D_ABLATE & 32)) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
+            }
+            const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 3) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = an[m];
+            }
+            if (q == 1 && c + kAhead + 1 < kChunks && !(DAD3D_ABLATE & 1)) DAD3D_ISSUE(c + kAhead + 1);
+            if (q == 3 && c + 2 < kChunks && !(DAD3D_ABLATE & 2)) DAD3D_COMMIT(c + 2);
+            // Hand-off from the pose role, off the critical path: look at the arrival counter once (chunk
+            // kChunks-5), tell the workgroup (kChunks-4), fetch the block with sc1 loads (kChunks-3), park it
+            // in LDS (kChunks-2); the barrier of the last chunk publishes it. Not ready yet -> blocking path below.
+            if (q == 6 && c == kChunks - 5 && tid == 0 && !(DAD3D_ABLATE & 16))
+                seen_early = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == 6 && c == kChunks - 4 && tid == 0 && !(DAD3D_ABLATE & 16)) *handoff_ok = ((int)(seen_early - a.arrive_target) >= 0) ? 1 : 0;
+            if (q == 1 && c == kChunks - 3 && !(DAD3D_ABLATE & 16)) {
+                early = *handoff_ok != 0;
+                if (early) {
+#pragma unroll
+                    for (int i = 0; i < kCst; ++i) {
+                        const int idx = i * 256 + tid;
+                        cst[i] = (idx < kVec) ? __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, idx * 16, 0, kCacheSc1)
+                                              : u32x4{0u, 0u, 0u, 0u};
+                    }
+                }
+            }
+            if (q == 5 && c == kChunks - 2 && early) {
+#pragma unroll
+                for (int i = 0; i < kCst; ++i)
+                    if (i * 256 + tid < kVec) reinterpret_cast<f32x4*>(imgc)[i * 256 + tid] = __builtin_bit_cast(f32x4, cst[i]);
+            }
+            if (q == 5 && c == 1 && !(DAD3D_ABLATE & 8)) {
+                // rows of the A image past the betas: pose feature (R_j - I), the template's 1, zero padding.
+                // 16 lanes per wave, one image each; published by the chunk barriers long before chunk 12.
+                if (lane < 16) {
+                    const int row = wave * 16 + lane;
+                    float* dst = a_lds + row * LD + kNumBeta;
+                    float tail[L::K - kNumBeta];
+#pragma unroll
+                    for (int i = 0; i < L::K - kNumBeta; ++i) tail[i] = 0.0f;
+                    if (tail_live) {
+                        float R[kNumJoints][9];
+                        joint_rotations(pose_in, a.lay, R);
+                        if (JAW_ONLY) {
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) tail[i] = R[2][i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+                            tail[9] = 1.0f;
+                        } else {
+#pragma unroll
+                            for (int jj = 1; jj < kNumJoints; ++jj)
+#pragma unroll
+                                for (int i = 0; i < 9; ++i)
+                                    tail[(jj - 1) * 9 + i] = R[jj][i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+                            tail[36] = 1.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < (L::K - kNumBeta) / 4; ++i)
+                        reinterpret_cast<float4*>(dst)[i] =
+                            float4{tail[4 * i], tail[4 * i + 1], tail[4 * i + 2], tail[4 * i + 3]};
+                }
+                if (tid < kTileVerts * 8) vconst[tid] = vc;
+                if (tid < kTileVerts) lmkh[tid] = lh;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef DAD3D_ISSUE
+#undef DAD3D_COMMIT
     stamp(3);
-    __syncthreads();  // all waves are done reading a_lds; reuse it for the output tile
 
-    // (4) accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
+    // accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             otile[(m * 16 + (lane >> 4) * 4 + q) * kOutStride + wave * 16 + (lane & 15)] = acc[m][q];
+
+    // ---- hand-off from the pose role, blocking path (the early look above found the block not yet published) --
+    // One lane polls the arrival counter (relaxed, agent scope) until every image of this launch has been
+    // published; the block is then fetched with sc1 loads (served by L2/memory, never a stale L1 line).
+    if (!early) {
+        if (tid == 0) {
+            int ok = 0;
+            for (unsigned spin = 0; spin < a.spin_limit; ++spin) {
+                const unsigned seen = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(seen - a.arrive_target) >= 0) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            *handoff_ok = ok;
+        }
+        __syncthreads();
+        if (*handoff_ok) {
+#pragma unroll
+            for (int i = 0; i < kCst; ++i) {
+                const int idx = i * 256 + tid;
+                if (idx < kVec) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, idx * 16, 0, kCacheSc1);
+                    reinterpret_cast<f32x4*>(imgc)[idx] = __builtin_bit_cast(f32x4, v);
+                }
+            }
+        } else {
+            // time-out (the pose role's workgroups were not scheduled in time): compute the block here
+            if (tid == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float* scr = a_lds + wave * 96;  // the A image is dead by now
+            for (int i = 0; i < 16; ++i) {
+                const int row = wave * 16 + i;
+                if (img0 + row < a.batch) {
+                    image_constants(a, a.params + (size_t)(img0 + row) * P, scr, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    for (int e = lane; e < kImgConsts; e += 64) imgc[row * kImgConsts + e] = scr[e];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                }
+            }
+        }
+    }
     __syncthreads();
     stamp(4);
 
-    // (5) epilogue: one (image, vertex) pair per thread-iteration; consecutive threads walk the
-    //     vertices of one image so HBM stores are contiguous runs of 21 x 12 B.
-    const int img0 = bb * kBlockImages;
-    const int v0 = tile * kTileVerts;
+    // ---- epilogue -------------------------------------------------------------------------------------
+    // Wave w finishes images [16w, 16w+16). A lane owns ONE vertex of the tile (its skinning weights stay
+    // in registers) and walks the images three at a time: lane = 21*g + j -> vertex j, image 3*it + g.
+    // Stores of one image are a contiguous run of 21 vertices.
+    const int j = lane % kTileVerts, g = lane / kTileVerts;
+    const int v = v0 + j;
+    const bool vlive = (g < 3) && (v < a.n_verts);
+    const float4 wa = reinterpret_cast<const float4*>(vconst)[j * 2];      // w0 w1 w2 w3
+    const float4 wb = reinterpret_cast<const float4*>(vconst)[j * 2 + 1];  // w4 S . .
+    const int lhead = lmkh[j];
+    // a vertex's landmark slots do not depend on the image: fetch the (almost always empty) tail once
+    const int lnext = (lhead >= 0) ? a.lmk_next[lhead] : -1;
     const bool to2d = (a.flags & DAD3D_TO_2D) != 0;
     const bool zero_rot = (a.flags & DAD3D_ZERO_ROTATION) != 0;
     const float zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
     const int pc = to2d ? 2 : 3;
-    for (int pidx = tid; pidx < kBlockImages * kTileVerts; pidx += 256) {
-        const int i = pidx / kTileVerts, j = pidx - i * kTileVerts;
-        const int b = img0 + i, v = v0 + j;
-        if (b >= a.batch || v >= a.n_verts) continue;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int li = 3 * it + g;
+        const int i = wave * 16 + li;
+        const int b = img0 + i;
+        if (!(vlive && li < 16 && b < a.batch)) continue;
         const float* o = otile + i * kOutStride + 3 * j;
         const float x = o[0], y = o[1], z = o[2];  // v_posed
-        const float4 w03 = *reinterpret_cast<const float4*>(a.weights8 + (size_t)v * 8);
-        const float w4 = a.weights8[(size_t)v * 8 + 4];
-        const float wj[kNumJoints] = {w03.x, w03.y, w03.z, w03.w, w4};
-        const float* c = imgc + i * kImgConsts;
-        // T = sum_j w_j A_j  (smplx lbs: W @ A), then T . [v_posed; 1]
-        float T[12];
+        const float4* c4p = reinterpret_cast<const float4*>(imgc + i * kImgConsts);
+        float px, py, pz;
+        if (JAW_ONLY) {
+            // only the jaw joint rotates: A_j = [I | t_j] for j != 2 (exactly), so
+            // T.[v;1] = S v + w2 (R_jaw v) + sum_j w_j t_j  with S = w0 + w1 + w3 + w4
+            const float4 r0 = c4p[0], r1 = c4p[1], r2 = c4p[2];        // A_2 rows
+            const float4 t01 = c4p[18], t13 = c4p[19], t34 = c4p[20];  // t0 t1 t3 t4 packed
+            const float S = wb.y, w2 = wa.z;
+            const float qx = r0.x * x + r0.y * y + r0.z * z + r0.w;
+            const float qy = r1.x * x + r1.y * y + r1.z * z + r1.w;
+            const float qz = r2.x * x + r2.y * y + r2.z * z + r2.w;
+            px = S * x + w2 * qx + (wa.x * t01.x + wa.y * t01.w + wa.w * t13.z + wb.x * t34.y);
+            py = S * y + w2 * qy + (wa.x * t01.y + wa.y * t13.x + wa.w * t13.w + wb.x * t34.z);
+            pz = S * z + w2 * qz + (wa.x * t01.z + wa.y * t13.y + wa.w * t34.x + wb.x * t34.w);
+        } else {
+            // T = sum_j w_j A_j (smplx lbs: W @ A), then T.[v_posed;1]; joint storage order 2,0,1,3,4
+            const float wj[kNumJoints] = {wa.z, wa.x, wa.y, wa.w, wb.x};
+            float T[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) {
-            float t = wj[0] * c[e];
+            for (int e4 = 0; e4 < 3; ++e4) {
+                float4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 1; q < kNumJoints; ++q) t += wj[q] * c[q * 12 + e];
-            T[e] = t;
+                for (int q = 0; q < kNumJoints; ++q) {
+                    const float4 aj = c4p[q * 3 + e4];
+                    t.x += wj[q] * aj.x, t.y += wj[q] * aj.y, t.z += wj[q] * aj.z, t.w += wj[q] * aj.w;
+                }
+                T[e4 * 4] = t.x, T[e4 * 4 + 1] = t.y, T[e4 * 4 + 2] = t.z, T[e4 * 4 + 3] = t.w;
+            }
+            px = T[0] * x + T[1] * y + T[2] * z + T[3];
+            py = T[4] * x + T[5] * y + T[6] * z + T[7];
+            pz = T[8] * x + T[9] * y + T[10] * z + T[11];
         }
-        float px = T[0] * x + T[1] * y + T[2] * z + T[3];
-        float py = T[4] * x + T[5] * y + T[6] * z + T[7];
-        float pz = T[8] * x + T[9] * y + T[10] * z + T[11];
         pz += kMeshOffsetZ;  // flame.py:224
-        const float rx = c[60] * px + c[61] * py + c[62] * pz;  // flame.py:226-228
-        const float ry = c[63] * px + c[64] * py + c[65] * pz;
-        const float rz = c[66] * px + c[67] * py + c[68] * pz;
+        const float4 ra = c4p[15], rb = c4p[16], rc = c4p[17];  // R (9) | s tx ty
+        const float rx = ra.x * px + ra.y * py + ra.z * pz;  // flame.py:226-228
+        const float ry = ra.w * px + rb.x * py + rb.y * pz;
+        const float rz = rb.z * px + rb.w * py + rc.x * pz;
         const size_t bv = (size_t)b * a.n_verts + v;
         if (a.verts3d) {
             float* d = a.verts3d + bv * 3;
@@ -329,25 +575,34 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
             d[2] = zero_rot ? pz : rz;
         }
         // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
-        const float s = c[69];
-        const float qx = (rx * s + c[70] + 1.0f) / 2.0f * a.image_size;
-        const float qy = (ry * s + c[71] + 1.0f) / 2.0f * a.image_size;
+        const float sc = rc.y;
+        const float ox = (rx * sc + rc.z + 1.0f) / 2.0f * a.image_size;
+        const float oy = (ry * sc + rc.w + 1.0f) / 2.0f * a.image_size;
         if (a.proj) {
             float* d = a.proj + bv * pc;
-            d[0] = qx;
-            d[1] = qy;
-            if (!to2d) d[2] = zsign * ((rz * s + 0.0f + 1.0f) / 2.0f * a.image_size);
+            d[0] = ox;
+            d[1] = oy;
+            if (!to2d) d[2] = zsign * ((rz * sc + 0.0f + 1.0f) / 2.0f * a.image_size);
         }
-        if (a.n_lmk > 0) {
-            for (int slot = a.lmk_head[v]; slot >= 0; slot = a.lmk_next[slot]) {
-                const size_t li = ((size_t)b * a.n_lmk + slot) * 2;
+        if (lhead >= 0) {
+            const size_t l0 = ((size_t)b * a.n_lmk + lhead) * 2;
+            if (a.lmk_xy) {
+                a.lmk_xy[l0] = ox;
+                a.lmk_xy[l0 + 1] = oy;
+            }
+            if (a.lmk_px) {  // numpy .astype(int): truncation toward zero
+                a.lmk_px[l0] = (int)ox;
+                a.lmk_px[l0 + 1] = (int)oy;
+            }
+            for (int slot = lnext; slot >= 0; slot = a.lmk_next[slot]) {  // duplicate indices in the list
+                const size_t li2 = ((size_t)b * a.n_lmk + slot) * 2;
                 if (a.lmk_xy) {
-                    a.lmk_xy[li] = qx;
-                    a.lmk_xy[li + 1] = qy;
+                    a.lmk_xy[li2] = ox;
+                    a.lmk_xy[li2 + 1] = oy;
                 }
-                if (a.lmk_px) {  // numpy .astype(int): truncation toward zero
-                    a.lmk_px[li] = (int)qx;
-                    a.lmk_px[li + 1] = (int)qy;
+                if (a.lmk_px) {
+                    a.lmk_px[li2] = (int)ox;
+                    a.lmk_px[li2 + 1] = (int)oy;
                 }
             }
         }
@@ -356,35 +611,30 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
 }
 
 size_t flame_decode_lds_bytes(int kgroups) {
-    return (size_t)(kgroups * 4 * 256 + kBlockImages * kImgConsts) * sizeof(float);
+    return (size_t)(kgroups == 26 ? DecodeLds<26>::total : DecodeLds<28>::total) * sizeof(float);
 }
 
-dad3d_status launch_flame_prologue(const PrologueArgs& a, hipStream_t s) {
-    const int nbb = (a.batch + kBlockImages - 1) / kBlockImages;
-    hipLaunchKernelGGL(flame_prologue_kernel, dim3(nbb * kBlockImages), dim3(64), 0, s, a);
-    DAD3D_HIP_TRY(hipGetLastError());
-    return DAD3D_OK;
-}
-
-template <int KG>
+template <int KG, bool JAW_ONLY, bool CONTIG>
 static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
     static bool attr_done = false;
     const size_t lds = flame_decode_lds_bytes(KG);
     if (!attr_done) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG, JAW_ONLY, CONTIG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    const int grid = a.n_tiles_pad8 * a.nbb;
-    hipLaunchKernelGGL(flame_decode_kernel<KG>, dim3(grid), dim3(256), lds, s, a);
+    const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8 * a.nbb;
+    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG>), dim3(grid), dim3(256), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }
 
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s) {
     switch (a.kgroups) {
-        case 26: return launch_decode_t<26>(a, s);  // K = 1 + 400 + 9 (jaw) -> 416
-        case 28: return launch_decode_t<28>(a, s);  // K = 1 + 400 + 36 (neck, jaw, eyes) -> 448
+        case 26:  // K = 400 + 9 (jaw only) + 1 -> 416
+            return a.betas_contiguous ? launch_decode_t<26, true, true>(a, s) : launch_decode_t<26, true, false>(a, s);
+        case 28:  // K = 400 + 36 (neck, jaw, eyes) + 1 -> 448
+            return a.betas_contiguous ? launch_decode_t<28, false, true>(a, s) : launch_decode_t<28, false, false>(a, s);
         default:
             set_error("no decode kernel instantiated for %d k-groups", a.kgroups);
             return DAD3D_E_UNSUPPORTED;

@@ -111,9 +111,12 @@ dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batc
  * summed milliseconds and launch count since the last `_read`, and resets them. */
 dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on);
 dad3d_status dad3d_flame_profile_read(dad3d_flame* h, double* total_ms, int* launches);
-/* Diagnostics: DEVICE buffer of [grid blocks][4 waves][8] uint64 that every wave of the fused kernel fills
+/* How many decode workgroups ever gave up waiting for the pose role's hand-off and recomputed the per-image
+ * constants themselves (still correct, slower). Expected 0; synchronises the device. */
+dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
+/* Diagnostics: DEVICE buffer of [grid blocks][4 waves][32] uint64 that every wave of the fused kernel fills
  * with shader-clock stamps at its phase boundaries (start, loads issued, operands landed, GEMM done, tile
- * staged, end); NULL switches it off. Grid blocks = 8*ceil(ceil(V/21)/8) * ceil(B/64). */
+ * staged, end; slots 8.. = one per staging chunk); NULL switches it off. Grid blocks = 8*ceil(ceil(V/21)/8) * ceil(B/64). */
 dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer);
 
 /* ------------------------------------------------------------------------------------------------

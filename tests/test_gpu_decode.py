@@ -196,3 +196,31 @@ def test_c_abi_host_entry_and_errors(hm, flame_consts):
     assert (dev.cpu() - ref).abs().max() < 1e-5
     assert lib.dad3d_flame_num_params(hm.flame._handle) == 413 and lib.dad3d_flame_num_verts(hm.flame._handle) == 5023
     assert lib.dad3d_flame_num_landmarks(hm.flame._handle) == 445
+
+
+def test_pose_handoff_under_back_to_back_launches(hm, flame_consts):
+    """The pose role hands its per-image block to the decode role inside ONE launch (sc1 stores + agent-scope
+    counter). Launch many batches of different sizes back to back, each overwriting the same hand-off buffer
+    with different contents (consumer caches warm with the previous launch's lines), and check every word of
+    a few images per launch against the oracle: a stale or missed hand-off cannot hide."""
+    import ctypes as C
+
+    rng = np.random.default_rng(123)
+    pending = []
+    for it in range(48):
+        batch = int(rng.choice([1, 3, 4, 5, 31, 64, 65, 127, 128, 200]))
+        params = synthetic.synthetic_params(batch, seed=5000 + it)
+        dev = torch.from_numpy(params).cuda()
+        out = hm.decode(dev, to_2d=True, landmarks=False)  # no sync between launches
+        pending.append((params, out))
+    torch.cuda.synchronize()
+    for params, out in pending:
+        rows = sorted(set([0, params.shape[0] - 1, int(rng.integers(0, params.shape[0]))]))
+        p = torch.from_numpy(params[rows].copy())
+        v_ref = flame_ref.vertices_3d(flame_consts, p).numpy()
+        p_ref = flame_ref.reprojected_vertices(flame_consts, p, to_2d=True).numpy()
+        assert np.abs(out["verts3d"][rows].cpu().numpy() - v_ref).max() < TOL_V
+        assert np.abs(out["proj"][rows].cpu().numpy() - p_ref).max() < TOL_PX
+    n = C.c_uint(99)
+    _lib.check(_lib.load().dad3d_flame_handoff_timeouts(hm.flame._handle, C.byref(n)))
+    assert n.value == 0, "decode workgroups fell back to computing the pose constants themselves"

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Diagnostics: build variants of libdad3d_hip.so with pieces of the fused decode kernel compiled out
+# (-DDAD3D_ABLATE=bits; results are WRONG, only the timing is meaningful) into tools/ablate/lib_<bits>.so.
+# Use with:  DAD3D_LIB_PATH=$PWD/tools/ablate/lib_<bits>.so python tools/trace_decode.py 64
+set -e
+cd "$(dirname "$0")/../dad-3dheads_amd/csrc"
+make -s
+mkdir -p ../../tools/ablate
+for n in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDAD3D_ABLATE=$n -c flame_decode.hip -o /tmp/fd_$n.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ablate/lib_$n.so /tmp/fd_$n.o sim3dr_kernels.o capi.o sim3dr_compat.o
+done

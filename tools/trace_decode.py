@@ -16,20 +16,23 @@ from dad_3dheads_amd import _lib, landmarks, synthetic  # noqa: E402
 from dad_3dheads_amd.head_mesh import HeadMesh  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dbg = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
 st = synthetic.load_static()
 hm = HeadMesh(flame_model=synthetic.synthetic_flame_model(0, st), landmarks=landmarks.canonical("445", st), static=st, device=0)
 p = torch.from_numpy(synthetic.synthetic_params(batch, seed=0)).cuda()
 nbb = (batch + 63) // 64
-grid = 240 * nbb
-trace = torch.zeros((grid, 4, 8), dtype=torch.int64, device="cuda")
+grid = 240 * nbb  # decode-role workgroups (the pose role is not traced)
+trace = torch.zeros((grid, 4, 32), dtype=torch.int64, device="cuda")
 lib = _lib.load()
 for _ in range(20):
     hm.decode(p, to_2d=True, landmarks_px=True)
 _lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, trace.data_ptr()))
-hm.decode(p, to_2d=True, landmarks_px=True)
+v3 = torch.empty((batch, 5023, 3), device="cuda"); pr = torch.empty((batch, 5023, 2), device="cuda"); lp = torch.empty((batch, 445, 2), dtype=torch.int32, device="cuda")
+_lib.check(lib.dad3d_flame_decode(hm.flame._handle, p.data_ptr(), batch, _lib.TO_2D | dbg, v3.data_ptr(), pr.data_ptr(), None, lp.data_ptr(), None))
 torch.cuda.synchronize()
 _lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None))
-t = trace.cpu().numpy().astype(np.float64)[..., :6]
+full = trace.cpu().numpy().astype(np.float64)
+t = full[..., :6]
 t0 = t[..., 0].min()
 names = ["issue loads", "wait operands", "GEMM", "stage tile", "epilogue"]
 d = np.diff(t, axis=-1)
