@@ -1,0 +1,76 @@
+"""Multi-GPU: images shard over ranks as independent batches; the only collective is the final gather.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the MI355X node; "gloo" on CPU
+for the tests). Nothing in the decode itself communicates: rank r owns the contiguous rows
+`shard_range(n, r, world)` of the global batch, the FLAME constants are replicated at construction, and
+`gather_rows` concatenates the per-rank results in rank order with ONE all-gather (ragged shards are padded
+to the largest shard for the collective and trimmed afterwards).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of an n-row batch owned by `rank`: contiguous, sizes differ by at most one, the first
+    `n % world` ranks get the extra row (BASELINE configs 4/5: 2048/8 = 256, 512/8 = 64)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(n: int, world: int) -> List[int]:
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+
+
+def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """All-gather row-sharded `local` ([n_r, ...], n_r = this rank's shard of n_total rows) into the full
+    `[n_total, ...]` tensor on every rank. One collective; works for any dtype the backend supports."""
+    if not dist.is_available() or not dist.is_initialized():
+        if local.shape[0] != n_total:
+            raise ValueError("single process: local must already hold every row")
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = shard_sizes(n_total, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} rows, its shard of {n_total} is {sizes[rank]}")
+    width = max(sizes)
+    if width == 0:
+        return local.new_empty((0,) + tuple(local.shape[1:]))
+    padded = local
+    if local.shape[0] != width:  # ragged: pad to the widest shard for the collective
+        padded = local.new_zeros((width,) + tuple(local.shape[1:]))
+        padded[: local.shape[0]] = local
+    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(s == width for s in sizes):
+        return out
+    return torch.cat([out[r * width : r * width + sizes[r]] for r in range(world)], dim=0)
+
+
+class ShardedLandmarkDecoder:
+    """Decode the rows this rank owns and gather the landmarks of the whole batch (BASELINE config 4)."""
+
+    def __init__(self, head_mesh, group: Optional[dist.ProcessGroup] = None):
+        self.head_mesh = head_mesh
+        self.group = group
+
+    def __call__(self, params_global: torch.Tensor) -> torch.Tensor:
+        """params_global [B,P] (every rank passes the same host/device tensor or just needs its own rows valid)
+        -> int32 landmarks [B, n_lmk, 2] on every rank."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        n = params_global.shape[0]
+        lo, hi = shard_range(n, rank, world)
+        dev = self.head_mesh.flame.torch_device
+        mine = params_global[lo:hi].to(dev, torch.float32).contiguous()
+        if hi > lo:
+            px = self.head_mesh.decode(mine, verts3d=False, proj=False, landmarks=False, landmarks_px=True)["lmk_px"]
+        else:
+            px = torch.empty((0, self.head_mesh.flame.n_landmarks, 2), dtype=torch.int32, device=dev)
+        return gather_rows(px, n, self.group)

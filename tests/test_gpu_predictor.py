@@ -1,0 +1,96 @@
+"""GPU: the FaceMeshPredictor drop-in (call surface of predictor.py:68-211) with a stand-in CNN -- the trained
+TorchScript checkpoint is not available offline, so the network is a deterministic module with the real
+output contract (flame_regression.py:96-104); everything after it is compared with the reference's CPU path."""
+import numpy as np
+import pytest
+import torch
+
+from dad_3dheads_amd import synthetic
+from dad_3dheads_amd.config import load_default_config
+from dad_3dheads_amd.predictor import FaceMeshPredictor, calculate_paddings, py3round
+from oracle import flame_ref
+
+pytestmark = pytest.mark.gpu
+
+
+class StandInRegressor(torch.nn.Module):
+    """Output contract of DAD-3DNet: {"3dmm_params": [B,413], "2d_landmarks": [B,68,2] in [0,1]}."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.register_buffer("w", torch.randn(3, 413, generator=g) * 0.5)
+        self.register_buffer("base", torch.from_numpy(synthetic.synthetic_params(1, seed=8))[0])
+
+    def forward(self, x):
+        feat = x.mean(dim=(2, 3))  # [B,3]
+        p = self.base[None] + 0.05 * torch.tanh(feat @ self.w)
+        lm = torch.sigmoid(feat[:, :2])[:, None, :].expand(-1, 68, -1) * torch.linspace(0.2, 0.9, 68, device=x.device)[None, :, None]
+        return {"3dmm_params": p, "2d_landmarks": lm}
+
+
+@pytest.fixture(scope="module")
+def predictor(flame_model):
+    return FaceMeshPredictor(load_default_config(), cuda_id=0, model=StandInRegressor(), flame_model=flame_model)
+
+
+def reference_postprocess(pred, image, flame_consts):
+    """predictor.py:102-176 on the CPU oracle, from the SAME network output."""
+    cache = {}
+    x = pred.preprocess(image, cache)
+    out = pred.process(x)
+    params = out["3dmm_params"].detach().cpu().clone()
+    lm = out["2d_landmarks"].detach().cpu().numpy() * 256.0
+    pads, scale = flame_ref.get_paddings(image.shape[:2])
+    pts = lm.clip(min=0, max=256) - np.array([[pads[2], pads[0]]])
+    pts = (pts / scale).astype(int).reshape(-1, 2)
+    params = flame_ref.readjust_3dmm(params, pads, scale)
+    v3d = flame_ref.vertices_3d(flame_consts, params)[0].squeeze()
+    proj = flame_ref.reprojected_vertices(flame_consts, params, to_2d=True)
+    return pts, proj, v3d, params
+
+
+@pytest.mark.parametrize("hw", [(256, 256), (954, 766), (300, 500), (100, 80)])
+def test_single_image_call_surface(predictor, flame_consts, hw):
+    rng = np.random.default_rng(hw[0])
+    image = rng.integers(0, 255, (hw[0], hw[1], 3), dtype=np.uint8)
+    res = predictor(image)
+    assert set(res) == {"points", "projected_vertices", "3d_vertices", "3dmm_params"}
+    assert res["points"].shape == (68, 2) and res["points"].dtype.kind == "i"
+    assert res["projected_vertices"].shape == (1, 5023, 2) and res["3d_vertices"].shape == (5023, 3)
+    assert res["3dmm_params"].shape == (1, 413) and res["3dmm_params"].device.type == "cpu"
+    pts, proj, v3d, params = reference_postprocess(predictor, image, flame_consts)
+    assert np.array_equal(res["points"], pts)
+    assert (res["3dmm_params"] - params).abs().max() < 1e-5 and res["3dmm_params"][0, 411] == 0
+    assert (res["3d_vertices"] - v3d).abs().max() < 5e-6
+    # pixels scale with 1/scale of the input frame (up to ~3.7x for the 954-pixel image)
+    assert (res["projected_vertices"] - proj).abs().max() < 1e-3 * max(1.0, max(hw) / 256)
+
+
+def test_geometry_of_demo_image(predictor):
+    pads, scale, (nh, nw) = predictor._geometry((954, 766))  # images/demo_heads/1.jpeg is 766x954 (WxH)
+    assert pads == [0, 0, 25, 25] and (nh, nw) == (256, 206) and abs(scale - 256 / 954) < 1e-12
+    assert py3round(2.5) == 2 and py3round(3.5) == 4 and calculate_paddings(206, 256) == [25, 25, 0, 0]
+    x = predictor.preprocess(np.zeros((954, 766, 3), np.uint8), {})
+    assert x.shape == (1, 3, 256, 256)
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+    assert np.allclose(x[0, :, 0, 0].cpu().numpy(), (0 - 255 * mean) / (255 * std), atol=1e-5)
+
+
+def test_batched_predictor_equals_single_calls(predictor):
+    rng = np.random.default_rng(3)
+    images = [rng.integers(0, 255, (h, w, 3), dtype=np.uint8) for h, w in ((256, 256), (300, 200), (128, 512), (256, 256), (90, 90))]
+    batched = predictor.predict_batch(images)
+    for im, b in zip(images, batched):
+        s = predictor(im)
+        assert np.array_equal(s["points"], b["points"])
+        for k in ("projected_vertices", "3d_vertices", "3dmm_params"):
+            assert torch.allclose(s[k], b[k], atol=2e-4, rtol=0)  # batch-size dependent conv/reduction order in the CNN
+    dev = predictor.predict_batch(images[:2], device_outputs=True)
+    assert dev[0]["3d_vertices"].is_cuda and dev[0]["projected_vertices"].is_cuda
+
+
+def test_missing_checkpoint_is_a_loud_error(flame_model, tmp_path, monkeypatch):
+    monkeypatch.setenv("HOME", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="no network"):
+        FaceMeshPredictor(load_default_config(), cuda_id=0, flame_model=flame_model)
