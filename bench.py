@@ -146,8 +146,8 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant-kernel duration: same K steps again with every fused-decode launch bracketed by hipEvents
-    # on the launch stream (kept out of the throughput region so the event records do not perturb `value`)
+    # dominant-kernel duration: the same K steps again, the run of back-to-back fused-decode launches bracketed
+    # by two hipEvents on the launch stream (a separate region so the event records do not perturb `value`)
     _lib.check(lib.dad3d_flame_profile_enable(handle, 1))
     for _ in range(args.steps):
         step()
@@ -188,7 +188,7 @@ def main() -> None:
                 "outputs_verified": ok,
             },
             "roofline": {
-                "kernel": "flame_decode_kernel<26>",
+                "kernel": "flame_decode_kernel<26,true,true> (pose role + decode role, one launch per step)",
                 "bound": "mfma",
                 "achieved": flops / kern_s / 1e12,
                 "peak": PEAK_FP32_MFMA_TFLOPS,

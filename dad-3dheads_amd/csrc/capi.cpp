@@ -56,8 +56,8 @@ struct dad3d_flame {
     int cap_nbb = 0;
     bool profiling = false;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
+    int prof_launches = 0;
 };
 
 static dad3d_status flame_reserve(dad3d_flame* h, int nbb) {
@@ -206,10 +206,8 @@ void dad3d_flame_destroy(dad3d_flame* h) {
     for (void* p : {(void*)h->d_bpack, (void*)h->d_jdirs, (void*)h->d_j0, (void*)h->d_w8, (void*)h->d_lmk_head,
                     (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc})
         if (p) (void)hipFree(p);
-    for (auto& e : h->ev_pool) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
+    if (h->ev_first) (void)hipEventDestroy(h->ev_first);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     delete h;
 }
 
@@ -287,21 +285,19 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     da.image_size = h->image_size;
     da.flags = flags;
     dad3d_status st;
-    if (h->profiling) {
-        if (h->ev_used == h->ev_pool.size()) {
-            hipEvent_t e0, e1;
-            DAD3D_HIP_TRY(hipEventCreate(&e0));
-            DAD3D_HIP_TRY(hipEventCreate(&e1));
-            h->ev_pool.emplace_back(e0, e1);
+    if (h->profiling && h->prof_launches == 0) {
+        if (!h->ev_first) {
+            DAD3D_HIP_TRY(hipEventCreate(&h->ev_first));
+            DAD3D_HIP_TRY(hipEventCreate(&h->ev_last));
         }
-        DAD3D_HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].first, s));
+        DAD3D_HIP_TRY(hipEventRecord(h->ev_first, s));
     }
     st = launch_flame_decode(da, s);
     if (st) return st;
     h->arrive_total = da.arrive_target;  // committed only once the launch was accepted
     if (h->profiling) {
-        DAD3D_HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used].second, s));
-        ++h->ev_used;
+        DAD3D_HIP_TRY(hipEventRecord(h->ev_last, s));  // re-recorded after every launch: the last one stands
+        ++h->prof_launches;
     }
     return DAD3D_OK;
 }
@@ -370,22 +366,22 @@ dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_
 dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on) {
     DAD3D_REQUIRE(h, "null handle");
     h->profiling = on != 0;
+    h->prof_launches = 0;
     return DAD3D_OK;
 }
 
 dad3d_status dad3d_flame_profile_read(dad3d_flame* h, double* total_ms, int* launches) {
     DAD3D_REQUIRE(h && total_ms && launches, "null argument");
     DeviceGuard guard(h->device);
-    double sum = 0.0;
-    for (size_t i = 0; i < h->ev_used; ++i) {
+    *total_ms = 0.0;
+    *launches = h->prof_launches;
+    if (h->prof_launches > 0) {
         float ms = 0.f;
-        DAD3D_HIP_TRY(hipEventSynchronize(h->ev_pool[i].second));
-        DAD3D_HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-        sum += ms;
+        DAD3D_HIP_TRY(hipEventSynchronize(h->ev_last));
+        DAD3D_HIP_TRY(hipEventElapsedTime(&ms, h->ev_first, h->ev_last));
+        *total_ms = ms;
     }
-    *total_ms = sum;
-    *launches = (int)h->ev_used;
-    h->ev_used = 0;
+    h->prof_launches = 0;
     return DAD3D_OK;
 }
 

@@ -116,88 +116,167 @@ __device__ __forceinline__ float beta_at(const float* p, const DecodeArgs& a, in
     return (l - a.max_shape < a.lay.expr_n) ? p[a.lay.expr_off + l - a.max_shape] : 0.0f;
 }
 
-// One wave computes the 84-float constant block of one image into `scr` (LDS, wave-private, >= 84 floats):
+// The 84-float constant block of one image:
 //   [0,60)  A_j rows 0..2 of the 4x4 relative transforms, joint order 2,0,1,3,4 (jaw first)
 //   [60,69) R from the 6-DoF vector     [69] s = max(scale+1, 1e-8)   [70,72) tx ty
 //   [72,84) the four non-jaw translations again, compact (jaw-only fast path of the epilogue)
-__device__ void image_constants(const DecodeArgs& a, const float* p, float* scr, int lane) {
-    float jacc[3 * kNumJoints];
-#pragma unroll
-    for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] = 0.0f;
-    for (int l = lane; l < a.n_betas; l += 64) {
-        const float beta = beta_at(p, a, l);
-#pragma unroll
-        for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] += a.jdirs[o * a.n_betas + l] * beta;
-    }
-    float J[kNumJoints][3];
-#pragma unroll
-    for (int o = 0; o < 3 * kNumJoints; ++o) J[o / 3][o % 3] = a.j0[o] + wave_sum(jacc[o]);
+// JAW_ONLY: neck and eyeball poses are size-0 inputs, so every joint but the jaw has R_j = I exactly and the
+// kinematic chain collapses to vector adds in the reference's own evaluation order.
+struct ImageScalars {  // the non-beta inputs of one image, loaded up front
+    PoseIn pose;
+    float rot6[6];
+    float scale, tx, ty;
+};
 
-    // ~600 flops of scalar work: every lane computes it redundantly (uniform loads), lane 0 writes it out
-    float R[kNumJoints][9];
-    joint_rotations(load_pose(p, a.lay), a.lay, R);
-    // kinematic chain (smplx batch_rigid_transform): world_j = world_parent . [R_j | J_j - J_parent]
+__device__ __forceinline__ ImageScalars load_scalars(const float* p, const ParamLayout& lay) {
+    ImageScalars s;
+    s.pose = load_pose(p, lay);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s.rot6[c] = p[lay.rot_off + c];
+    s.scale = p[lay.scale_off];
+    s.tx = p[lay.trans_off];
+    s.ty = p[lay.trans_off + 1];
+    return s;
+}
+
+// joints + pose inputs -> the block, in registers (a few hundred flops; every lane computes it redundantly)
+template <bool JAW_ONLY>
+__device__ __forceinline__ void constants_from_joints(const DecodeArgs& a, const float J[kNumJoints][3],
+                                                      const ImageScalars& in, float out[kImgConsts]) {
     float WR[kNumJoints][9], Wt[kNumJoints][3];
+    if (JAW_ONLY) {
+        // world_j = world_parent . [R_j | J_j - J_parent] with R_j = I except the jaw
+        float Rj[9];
+        if (a.lay.jaw_n == 3) rodrigues(in.pose.jaw, Rj); else identity3(Rj);
 #pragma unroll
-    for (int j = 0; j < kNumJoints; ++j) {
-        if (j == 0) {
+        for (int j = 0; j < kNumJoints; ++j) {
+            if (j == 2) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) WR[j][i] = R[j][i];
+                for (int i = 0; i < 9; ++i) WR[j][i] = Rj[i];
+            } else {
+                identity3(WR[j]);
+            }
+        }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Wt[j][c] = J[j][c];
-        } else {
-            // parents are < j for a valid kinematic tree; select without dynamic register indexing
-            float PR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Pt[3] = {0, 0, 0}, Jp[3] = {0, 0, 0};
+        for (int c = 0; c < 3; ++c) Wt[0][c] = J[0][c];
+#pragma unroll
+        for (int j = 1; j < kNumJoints; ++j) {
+            // parent of 1 is 0, of 2,3,4 is 1 for FLAME; generic select keeps any valid tree working. The
+            // parent's rotation is I for every parent that is not the jaw (a jaw parent is not jaw-only).
+            float Pt[3] = {0, 0, 0}, Jp[3] = {0, 0, 0};
 #pragma unroll
             for (int q = 0; q < kNumJoints; ++q)
                 if (q < j && q == a.parents[j]) {
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) PR[i] = WR[q][i];
-#pragma unroll
                     for (int c = 0; c < 3; ++c) Pt[c] = Wt[q][c], Jp[c] = J[q][c];
                 }
-            const float rel[3] = {J[j][0] - Jp[0], J[j][1] - Jp[1], J[j][2] - Jp[2]};
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) Wt[j][c] = (J[j][c] - Jp[c]) + Pt[c];
+        }
+    } else {
+        float R[kNumJoints][9];
+        joint_rotations(in.pose, a.lay, R);
+        // kinematic chain (smplx batch_rigid_transform): world_j = world_parent . [R_j | J_j - J_parent]
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    WR[j][r * 3 + c] = PR[r * 3] * R[j][c] + PR[r * 3 + 1] * R[j][3 + c] + PR[r * 3 + 2] * R[j][6 + c];
-                Wt[j][r] = PR[r * 3] * rel[0] + PR[r * 3 + 1] * rel[1] + PR[r * 3 + 2] * rel[2] + Pt[r];
+        for (int j = 0; j < kNumJoints; ++j) {
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) WR[j][i] = R[j][i];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Wt[j][c] = J[j][c];
+            } else {
+                // parents are < j for a valid kinematic tree; select without dynamic register indexing
+                float PR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Pt[3] = {0, 0, 0}, Jp[3] = {0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < kNumJoints; ++q)
+                    if (q < j && q == a.parents[j]) {
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) PR[i] = WR[q][i];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) Pt[c] = Wt[q][c], Jp[c] = J[q][c];
+                    }
+                const float rel[3] = {J[j][0] - Jp[0], J[j][1] - Jp[1], J[j][2] - Jp[2]};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        WR[j][r * 3 + c] = PR[r * 3] * R[j][c] + PR[r * 3 + 1] * R[j][3 + c] + PR[r * 3 + 2] * R[j][6 + c];
+                    Wt[j][r] = PR[r * 3] * rel[0] + PR[r * 3 + 1] * rel[1] + PR[r * 3 + 2] * rel[2] + Pt[r];
+                }
             }
         }
     }
     // 6-DoF -> rotation (model/utils.py:92-101), columns b1 b2 b3
-    float b1[3] = {p[a.lay.rot_off], p[a.lay.rot_off + 1], p[a.lay.rot_off + 2]};
-    const float vy[3] = {p[a.lay.rot_off + 3], p[a.lay.rot_off + 4], p[a.lay.rot_off + 5]};
+    float b1[3] = {in.rot6[0], in.rot6[1], in.rot6[2]};
+    const float vy[3] = {in.rot6[3], in.rot6[4], in.rot6[5]};
     normalize3(b1);
     float b3[3] = {b1[1] * vy[2] - b1[2] * vy[1], b1[2] * vy[0] - b1[0] * vy[2], b1[0] * vy[1] - b1[1] * vy[0]};
     normalize3(b3);
     const float b2[3] = {-(b1[1] * b3[2] - b1[2] * b3[1]), -(b1[2] * b3[0] - b1[0] * b3[2]),
                          -(b1[0] * b3[1] - b1[1] * b3[0])};
-    if (lane == 0) {
-        // A_j = world_j - [0 | world_j . J_j]
+    // A_j = world_j - [0 | world_j . J_j]
 #pragma unroll
-        for (int j = 0; j < kNumJoints; ++j) {
-            const int slot = (j == 2) ? 0 : (j < 2 ? j + 1 : j);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) scr[slot * 12 + r * 4 + c] = WR[j][r * 3 + c];
-                const float t =
-                    Wt[j][r] - (WR[j][r * 3] * J[j][0] + WR[j][r * 3 + 1] * J[j][1] + WR[j][r * 3 + 2] * J[j][2]);
-                scr[slot * 12 + r * 4 + 3] = t;
-                if (slot > 0) scr[72 + (slot - 1) * 3 + r] = t;
-            }
-        }
+    for (int j = 0; j < kNumJoints; ++j) {
+        const int slot = (j == 2) ? 0 : (j < 2 ? j + 1 : j);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            scr[60 + r * 3 + 0] = b1[r];
-            scr[60 + r * 3 + 1] = b2[r];
-            scr[60 + r * 3 + 2] = b3[r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[slot * 12 + r * 4 + c] = WR[j][r * 3 + c];
+            const float t = Wt[j][r] - (WR[j][r * 3] * J[j][0] + WR[j][r * 3 + 1] * J[j][1] + WR[j][r * 3 + 2] * J[j][2]);
+            out[slot * 12 + r * 4 + 3] = t;
+            if (slot > 0) out[72 + (slot - 1) * 3 + r] = t;
         }
-        scr[69] = fmaxf(p[a.lay.scale_off] + 1.0f, 1e-8f);  // head_mesh.py:39
-        scr[70] = p[a.lay.trans_off];
-        scr[71] = p[a.lay.trans_off + 1];  // translation z := 0 (head_mesh.py:41)
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        out[60 + r * 3 + 0] = b1[r];
+        out[60 + r * 3 + 1] = b2[r];
+        out[60 + r * 3 + 2] = b3[r];
+    }
+    out[69] = fmaxf(in.scale + 1.0f, 1e-8f);  // head_mesh.py:39
+    out[70] = in.tx;
+    out[71] = in.ty;  // translation z := 0 (head_mesh.py:41)
+}
+
+// this lane's float4 of the betas (lane + 64*pass), zero past the end
+template <bool CONTIG>
+__device__ __forceinline__ float4 lane_betas(const DecodeArgs& a, const float* p, int l) {
+    if (l >= a.n_betas) return float4{0.f, 0.f, 0.f, 0.f};
+    if (CONTIG) {
+        const f4u v = *reinterpret_cast<const f4u*>(p + l);
+        return float4{v.x, v.y, v.z, v.w};
+    }
+    return float4{beta_at(p, a, l), beta_at(p, a, l + 1), beta_at(p, a, l + 2), beta_at(p, a, l + 3)};
+}
+
+// Stand-alone form (used only when a decode workgroup gave up waiting for the pose role): one wave computes
+// the block of one image straight from global memory and lane 0 writes it to `dst` (LDS).
+template <bool JAW_ONLY, bool CONTIG>
+__device__ void image_constants(const DecodeArgs& a, const float* p, float* dst, int lane) {
+    const ImageScalars in = load_scalars(p, a.lay);
+    float jacc[3 * kNumJoints];
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] = 0.0f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int l = 4 * (lane + 64 * pass);
+        const float4 be = lane_betas<CONTIG>(a, p, l);
+        if (l < a.n_betas) {
+#pragma unroll
+            for (int o = 0; o < 3 * kNumJoints; ++o) {
+                const float4 jd = *reinterpret_cast<const float4*>(a.jdirs + o * a.n_betas + l);
+                jacc[o] += jd.x * be.x + jd.y * be.y + jd.z * be.z + jd.w * be.w;
+            }
+        }
+    }
+    float J[kNumJoints][3];
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) J[o / 3][o % 3] = a.j0[o] + wave_sum(jacc[o]);
+    float out[kImgConsts];
+    constants_from_joints<JAW_ONLY>(a, J, in, out);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < kImgConsts; ++i) dst[i] = out[i];
     }
 }
 
@@ -207,34 +286,118 @@ struct DecodeLds {
     static constexpr int K = KG * 16;
     static constexpr int LD = (KG == 26) ? 424 : 456;  // row stride: ds_read_b128 of the A operand conflict-free
     static constexpr int a_off = 0;                    // [64 images][LD]
-    static constexpr int imgc_off = kBlockImages * LD; // [64][kImgConsts]
+    static constexpr int imgc_off = kBlockImages * LD;                   // [64][kImgConsts]
     static constexpr int vc_off = imgc_off + kBlockImages * kImgConsts;  // [21][8] skinning weights
-    static constexpr int lh_off = vc_off + kTileVerts * 8;               // [24] landmark heads (+ hand-off flag)
-    static constexpr int o_off = lh_off + 24;                            // [64][kOutStride] accumulator tile
+    static constexpr int lh_off = vc_off + kTileVerts * 8;               // [32] ints: 21 landmark heads, 3 part counters, hand-off flag
+    static constexpr int o_off = lh_off + 32;                            // [64][kOutStride] accumulator tile
     static constexpr int total = o_off + kBlockImages * kOutStride;
+    static_assert(total * 4 <= 160 * 1024, "LDS budget of one CU");
 };
 
 // ------------------------------------------------------------------------------------------------------
 // pose role
 // ------------------------------------------------------------------------------------------------------
+// One workgroup (4 waves) = 4 images, one per wave. The joint regression J = J0 + Jdirs.betas is 15 dot products of
+// length 400 per image: Jdirs (24 KB, the same for every image) is staged once per workgroup in LDS, each lane
+// multiplies its 8 betas against it, and the 15 x 64 partial sums are reduced through LDS by 15 lanes (a 6-step
+// ds_bpermute butterfly per value measured 4x slower). Everything else is scalar math every lane does redundantly;
+// lane l < 21 then keeps float4 number l of the block and stores it write-through.
+template <bool JAW_ONLY, bool CONTIG>
 __device__ void pose_role(const DecodeArgs& a, float* smem) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x * 4 + wave;
-    if (b >= a.batch) return;
-    float* scr = smem + wave * 96;
-    float* p = a.params + (size_t)b * a.lay.n_params;
-    image_constants(a, p, scr, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 0's LDS writes before the other lanes read
+    const bool live = b < a.batch;
+    float* jd = smem;                                         // [15][400]
+    float* partial = smem + 3 * kNumJoints * 400 + wave * 1152;  // [64 lanes][17] per wave, 16 sums at [1120,1136)
+    float* p = a.params + (size_t)min(b, a.batch - 1) * a.lay.n_params;
+    unsigned long long* trace =
+        a.trace ? a.trace + ((size_t)a.n_tiles_pad8 * a.nbb * 8 + (size_t)blockIdx.x * 4 + wave) * 32 : nullptr;
+    if (trace && lane == 0) trace[0] = __builtin_readcyclecounter(), trace[12] = wall_clock64();
+    // all loads of the workgroup in flight together: Jdirs (6 float4 per thread), this image's betas and scalars
+    constexpr int kJdVec = 3 * kNumJoints * 400 / 4;
+    float4 jdv[(kJdVec + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (kJdVec + 255) / 256; ++i) {
+        const int idx = i * 256 + tid;
+        jdv[i] = idx < kJdVec ? reinterpret_cast<const float4*>(a.jdirs)[idx] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const ImageScalars in = load_scalars(p, a.lay);
+    const float4 be0 = lane_betas<CONTIG>(a, p, 4 * lane), be1 = lane_betas<CONTIG>(a, p, 4 * (lane + 64));
+    float j0v[3 * kNumJoints];
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) j0v[o] = a.j0[o];
+#pragma unroll
+    for (int i = 0; i < (kJdVec + 255) / 256; ++i)
+        if (i * 256 + tid < kJdVec) reinterpret_cast<float4*>(jd)[i * 256 + tid] = jdv[i];
+    __syncthreads();
+    if (!live) return;
+    float out[kImgConsts];
+#pragma unroll 1
+    for (int rep = 0; rep < ((DAD3D_ABLATE & 64) ? 2 : 1); ++rep) {  // diagnostics: second pass = warm instruction cache
+    if (rep == 1 && trace && lane == 0) trace[6] = __builtin_readcyclecounter();
+    if (trace && lane == 0) trace[4] = __builtin_readcyclecounter();
+    // dot products: lane owns betas [4*lane, 4*lane+4) and [256 + 4*lane, ...); past the 400th beta the lane's
+    // betas are zero and the Jdirs address is clamped into the row, so there is no branch in this loop
+    float jacc[3 * kNumJoints];
+    const int l1 = 256 + min(4 * lane, 140);
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) {
+        const float4 d0 = *reinterpret_cast<const float4*>(jd + o * 400 + 4 * lane);
+        const float4 d1 = *reinterpret_cast<const float4*>(jd + o * 400 + l1);
+        jacc[o] = (d0.x * be0.x + d0.y * be0.y + d0.z * be0.z + d0.w * be0.w) +
+                  (d1.x * be1.x + d1.y * be1.y + d1.z * be1.z + d1.w * be1.w);
+    }
+    // reduction over the 64 lanes through LDS, all lanes busy and bank-conflict free: partials at [lane][17],
+    // lane (o = lane & 15, h = lane >> 4) sums value o of lanes 16h..16h+15, two butterfly steps join the h
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) partial[lane * 17 + o] = jacc[o];
+    partial[lane * 17 + 15] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (rep == 1 && trace && lane == 0) trace[8] = __builtin_readcyclecounter();
+    {
+        const int o = lane & 15, h = lane >> 4;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            t0 += partial[(h * 16 + i) * 17 + o];
+            t1 += partial[(h * 16 + i + 1) * 17 + o];
+            t2 += partial[(h * 16 + i + 2) * 17 + o];
+            t3 += partial[(h * 16 + i + 3) * 17 + o];
+        }
+        float t = (t0 + t1) + (t2 + t3);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane < 16) partial[1120 + lane] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    float J[kNumJoints][3];
+    {
+        const float4* sums = reinterpret_cast<const float4*>(partial + 1120);
+        const float4 q0 = sums[0], q1 = sums[1], q2 = sums[2], q3 = sums[3];
+        const float sv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+        for (int o = 0; o < 3 * kNumJoints; ++o) J[o / 3][o % 3] = j0v[o] + sv[o];
+    }
+    if (trace && lane == 0) trace[5] = __builtin_readcyclecounter();
+    if (rep == 1 && trace && lane == 0) trace[9] = __builtin_readcyclecounter();
+    constants_from_joints<JAW_ONLY>(a, J, in, out);
+    if (rep == 1 && trace && lane == 0) trace[7] = __builtin_readcyclecounter();
+    }
+    if (trace && lane == 0) trace[1] = __builtin_readcyclecounter();
     if (lane == 0 && (a.flags & DAD3D_MUTATE_PARAMS)) p[a.lay.trans_off + 2] = 0.0f;  // head_mesh.py:41
     // publish: write-through (sc1) 16-byte stores, drained, then ONE relaxed agent-scope arrival
+    f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kImgConsts / 4; ++i)
+        if (lane == i) mine = f32x4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.imgc + (size_t)b * kImgConsts, 0, kImgConsts * (int)sizeof(float), 0x00020000);
-    if (lane < kImgConsts / 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(scr + lane * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, lane * 16, 0, kCacheSc1);
-    }
+    if (lane < kImgConsts / 4)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine), rsrc, lane * 16, 0, kCacheSc1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (trace && lane == 0) trace[2] = __builtin_readcyclecounter();
     if (lane == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (trace && lane == 0) trace[3] = __builtin_readcyclecounter(), trace[13] = wall_clock64();
 }
 
 }  // namespace
@@ -242,19 +405,32 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
 // ------------------------------------------------------------------------------------------------------
 // the fused kernel
 // ------------------------------------------------------------------------------------------------------
+// Decode-role workgroup = 8 waves. Waves 0-3 ("mma", one per SIMD) request their whole basis slice (26 x 1 KiB
+// per wave, fragment-ordered by the host) into VGPRs up front and then do nothing but ds_read + MFMA. Waves 4-7
+// ("feeders", one per SIMD beside an mma wave) copy the 64 params rows into the row-major A image in four
+// parts of growing size (6, 8 and the remaining MFMA groups), write the pose-feature rows, and fetch the
+// pose role's block -- so global-load latency, vmcnt waits and ds_write issue never sit in an MFMA wave's
+// instruction stream, the GEMM starts after 3/13 of A has landed, and only three workgroup barriers (one per
+// part, each placed one group before the part's first use so the fragment prefetch can cross it) interrupt it.
+//
 // CONTIG: params[:, 0:400] are the betas (shape == 300, expression == 100: the dad_3dnet.yaml constants), so
 // the A operand is copied with 16-byte loads; otherwise it is gathered element by element (flame.py:192-200).
+template <int KG>
+struct Parts {  // A-image parts in MFMA groups of 16 k: [0,6) [6,14) [14,KG)
+    static constexpr int n = 3;
+    static constexpr int begin(int p) { return p == 0 ? 0 : p == 1 ? 6 : p == 2 ? 14 : KG; }
+};
+
 template <int KG, bool JAW_ONLY, bool CONTIG>
-__global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
+__global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < a.n_pose_blocks_pad8) {
-        if ((int)blockIdx.x < a.n_pose_blocks) pose_role(a, smem);
+        if ((int)blockIdx.x < a.n_pose_blocks && threadIdx.x < 256) pose_role<JAW_ONLY, CONTIG>(a, smem);
         return;
     }
     using L = DecodeLds<KG>;
+    using PT = Parts<KG>;
     constexpr int LD = L::LD;
-    constexpr int kChunks = KG / 2;   // staging granule: 32 k = 2 MFMA groups = 8 k-steps
-    constexpr int kAhead = 3;         // staging registers hold 3 chunks (named ring below)
     constexpr int kNumBeta = 400;     // MAX_SHAPE + MAX_EXPRESSION, checked on the host
     float* a_lds = smem + L::a_off;
     float* imgc = smem + L::imgc_off;
@@ -270,157 +446,156 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
     const int bb = rr % a.nbb;
     const int tile = (rr / a.nbb) * 8 + xcd;
     if (tile >= a.n_tiles) return;
-    unsigned long long* trace = a.trace ? a.trace + ((size_t)gid * 4 + wave) * 32 : nullptr;
+    unsigned long long* trace = a.trace ? a.trace + ((size_t)gid * 8 + wave) * 32 : nullptr;
     auto stamp = [&](int slot) {
         if (trace && lane == 0) trace[slot] = __builtin_readcyclecounter();
     };
     stamp(0);
+    if (trace && lane == 0) trace[12] = wall_clock64();
     const int img0 = bb * kBlockImages;
     const int v0 = tile * kTileVerts;
     const int P = a.lay.n_params;
 
-    // ---- operand streams ----------------------------------------------------------------------------
-    // B: wave-private 16 columns, fragment-ordered on the host, 1 KiB per load, straight to VGPRs.
-    const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
-    // A: thread copies float4 (row, 4*c4 + 32*chunk) for rows srow and srow+32 of the 64 params rows.
-    const int srow = tid >> 3, c4 = tid & 7;
-    const bool live0 = img0 + srow < a.batch, live1 = img0 + srow + 32 < a.batch;
-    const float* prow0 = a.params + (size_t)(img0 + srow) * P;
-    const float* prow1 = a.params + (size_t)(img0 + srow + 32) * P;
-    float* adst0 = a_lds + srow * LD + 4 * c4;
-    float* adst1 = adst0 + 32 * LD;
-    auto beta4 = [&](const float* prow, bool live, int k) -> float4 {
-        float4 r = {0.f, 0.f, 0.f, 0.f};
-        if (live && k < kNumBeta) {
-            if (CONTIG) {
-                const f4u v = *reinterpret_cast<const f4u*>(prow + k);
-                r = float4{v.x, v.y, v.z, v.w};
-            } else {
-                r = float4{beta_at(prow, a, k), beta_at(prow, a, k + 1), beta_at(prow, a, k + 2), beta_at(prow, a, k + 3)};
-            }
-        }
-        return r;
-    };
-    float4 bq[KG];
-    float4 sa0, sb0, sa1, sb1, sa2, sb2;  // staging ring, named (an indexed array ends up in scratch)
-    static_assert(kAhead == 3, "the staging ring below is written out for 3 chunks in flight");
-    // k >= 400 (pose feature, template row, zero padding) is written by the tail code, not staged
-#define DAD3D_ISSUE(c)                                                          \
-    do {                                                                        \
-        bq[2 * (c)] = bsrc[(size_t)(2 * (c)) * 256];                            \
-        bq[2 * (c) + 1] = bsrc[(size_t)(2 * (c) + 1) * 256];                    \
-        if (32 * (c) < kNumBeta) {                                              \
-            const float4 la = beta4(prow0, live0, 32 * (c) + 4 * c4);           \
-            const float4 lb = beta4(prow1, live1, 32 * (c) + 4 * c4);           \
-            if ((c) % 3 == 0) sa0 = la, sb0 = lb;                               \
-            else if ((c) % 3 == 1) sa1 = la, sb1 = lb;                          \
-            else sa2 = la, sb2 = lb;                                            \
-        }                                                                       \
-    } while (0)
-#define DAD3D_COMMIT(c)                                                                            \
-    do {                                                                                           \
-        if (32 * (c) < kNumBeta && 32 * (c) + 4 * c4 < kNumBeta) {                                 \
-            *reinterpret_cast<float4*>(adst0 + 32 * (c)) = (c) % 3 == 0 ? sa0 : (c) % 3 == 1 ? sa1 : sa2; \
-            *reinterpret_cast<float4*>(adst1 + 32 * (c)) = (c) % 3 == 0 ? sb0 : (c) % 3 == 1 ? sb1 : sb2; \
-        }                                                                                          \
-    } while (0)
-#pragma unroll
-    for (int c = 0; c < kAhead; ++c) DAD3D_ISSUE(c);
-    // pose inputs of image (16*wave + lane) for the A rows past the betas: loaded now, used after chunk 1
-    PoseIn pose_in{};
-    const bool tail_live = lane < 16 && img0 + wave * 16 + lane < a.batch;
-    if (tail_live) pose_in = load_pose(a.params + (size_t)(img0 + wave * 16 + lane) * P, a.lay);
-    // per-vertex constants of the tile: loaded now, parked in LDS mid-GEMM, used by the epilogue
-    float vc = 0.0f;
-    int lh = -1;
-    if (tid < kTileVerts * 8) {
-        const int v = v0 + tid / 8;
-        vc = (v < a.n_verts) ? a.weights8[(size_t)v * 8 + (tid & 7)] : 0.0f;
-    }
-    if (tid < kTileVerts && v0 + tid < a.n_verts && a.n_lmk > 0) lh = a.lmk_head[v0 + tid];
-    __builtin_amdgcn_sched_barrier(0);
-    stamp(1);
-    DAD3D_COMMIT(0);
-    DAD3D_ISSUE(kAhead);  // reuses chunk 0's staging registers, hence after its commit
-    DAD3D_COMMIT(1);
+    // Feeder -> mma publication without workgroup barriers: part p of the A image is ready when its LDS
+    // counter reaches 4 (one arrival per feeder wave, added after that wave's ds_writes have completed).
+    // The feeders therefore never wait for the mma waves and the mma waves only ever poll a counter.
+    // (LDS address space spelled out: through a generic volatile pointer these become FLAT accesses that queue
+    // behind the wave's outstanding global loads)
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int* part_ready = (lds_int*)(lmkh + 21);  // lmkh[0..20] = landmark heads of the 21 vertices
+    lds_int* handoff_flag = (lds_int*)(lmkh + 24);  // 0 = pending, 1 = published, 2 = timed out
+    if (tid < 4) __hip_atomic_store(part_ready + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // [3] = the flag
     __syncthreads();
-    stamp(2);
+    auto lds_peek = [](lds_int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto wait_part = [&](int p) {
+        while (lds_peek(part_ready + p) < 4) __builtin_amdgcn_s_sleep(1);
+    };
+    auto publish_part = [&](int p) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the part have landed
+        if (lane == 0) __hip_atomic_fetch_add(part_ready + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
-    // ---- GEMM ---------------------------------------------------------------------------------------
-    // acc[m] = images [16m,16m+16) x columns [16*wave,16*wave+16). MFMA step (G, s): lane group q = lane>>4
-    // contributes basis row k = 16G + 4q + s, so the A operand of lane (q, i) for s = 0..3 is the float4
-    // at a_lds[16m + i][16G + 4q]. The fragments of group G+1 are read while group G multiplies.
-    constexpr int kVec = kBlockImages * kImgConsts / 4;  // float4s of this block's per-image constants
-    constexpr int kCst = (kVec + 255) / 256;
-    const __amdgpu_buffer_rsrc_t imgc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.imgc + (size_t)img0 * kImgConsts, 0, min(kBlockImages, a.batch - img0) * kImgConsts * (int)sizeof(float),
-        0x00020000);  // rows past the batch read as zeros (buffer bounds check)
-    int* handoff_ok = lmkh + 23;
-    unsigned seen_early = 0;
-    bool early = false;
-    u32x4 cst[kCst];
-    f32x4 acc[4];
+    if (wave < 4) {
+        // =============================== mma waves ===============================================
+        // acc[m] = images [16m,16m+16) x columns [16*wave,16*wave+16). MFMA step (G, s): lane group
+        // q = lane>>4 contributes basis row k = 16G + 4q + s, so the A operand of lane (q, i) for s = 0..3 is
+        // the float4 at a_lds[16m + i][16G + 4q], and its B operand the float4 the host packed for (G, wave,
+        // lane). The A fragments of group G+1 are read while group G multiplies.
+        const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
+        // the basis slice of this wave: kBAhead groups (1 KiB each) requested up front, then one more per group
+        // multiplied -- the texture-address unit (64 B/clk) is shared with the feeders, whose first part
+        // must not queue behind 100 KiB of basis that is not needed for thousands of cycles
+        constexpr int kBAhead = 6;
+        float4 bq[KG];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* afrag = a_lds + (lane & 15) * LD + 4 * (lane >> 4);
-    float4 af[4], an[4] = {};
+        for (int G = 0; G < kBAhead && G < KG; ++G) bq[G] = bsrc[(size_t)G * 256];
+        f32x4 acc[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
-    // Per chunk (2 groups = 32 MFMAs = 1024 cycles of the matrix pipe): after step 1 the loads of chunk c+4
-    // are issued, after step 3 chunk c+2 goes from the staging registers to LDS -- half a chunk before the
-    // barrier that publishes it, so neither the ds_writes nor their lgkmcnt drain sit on the MFMA path.
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* afrag = a_lds + (lane & 15) * LD + 4 * (lane >> 4);
+        float4 af[4], an[4] = {};
+        stamp(1);
+        wait_part(0);  // part 0 of the A image is in LDS
+        stamp(2);
 #pragma unroll
-    for (int c = 0; c < kChunks; ++c) {
-        if (c > 0 && !(DAD3D_ABLATE & 4)) __syncthreads();  // chunk c+1 (written during chunk c-1) is now visible to every wave
+        for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int G = 2 * c + (q >> 2), s = q & 3;
-            if (s == 0 && G + 1 < KG && !(DAD3D_ABLATE & 32)) {
+        for (int G = 0; G < KG; ++G) {
+            // part p is awaited one group before its first group: the prefetch below (group G+1) then always
+            // reads published data
+            if (G + 1 == PT::begin(1) || G + 1 == PT::begin(2)) {
+                if (DAD3D_ABLATE & 64) stamp(8 + 2 * (G + 1 == PT::begin(1) ? 0 : 1));
+                wait_part(G + 1 == PT::begin(1) ? 1 : 2);
+                if (DAD3D_ABLATE & 64) stamp(9 + 2 * (G + 1 == PT::begin(1) ? 0 : 1));
+            }
+            if ((DAD3D_ABLATE & 64) && G == 20) stamp(14);
+            if (G + 1 < KG) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
             }
-            const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == 3) {
+            for (int s = 0; s < 4; ++s) {
+                const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = an[m];
-            }
-            if (q == 1 && c + kAhead + 1 < kChunks && !(DAD3D_ABLATE & 1)) DAD3D_ISSUE(c + kAhead + 1);
-            if (q == 3 && c + 2 < kChunks && !(DAD3D_ABLATE & 2)) DAD3D_COMMIT(c + 2);
-            // Hand-off from the pose role, off the critical path: look at the arrival counter once (chunk
-            // kChunks-5), tell the workgroup (kChunks-4), fetch the block with sc1 loads (kChunks-3), park it
-            // in LDS (kChunks-2); the barrier of the last chunk publishes it. Not ready yet -> blocking path below.
-            if (q == 6 && c == kChunks - 5 && tid == 0 && !(DAD3D_ABLATE & 16))
-                seen_early = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q == 6 && c == kChunks - 4 && tid == 0 && !(DAD3D_ABLATE & 16)) *handoff_ok = ((int)(seen_early - a.arrive_target) >= 0) ? 1 : 0;
-            if (q == 1 && c == kChunks - 3 && !(DAD3D_ABLATE & 16)) {
-                early = *handoff_ok != 0;
-                if (early) {
-#pragma unroll
-                    for (int i = 0; i < kCst; ++i) {
-                        const int idx = i * 256 + tid;
-                        cst[i] = (idx < kVec) ? __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, idx * 16, 0, kCacheSc1)
-                                              : u32x4{0u, 0u, 0u, 0u};
-                    }
+                for (int m = 0; m < 4; ++m) {
+                    const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
                 }
             }
-            if (q == 5 && c == kChunks - 2 && early) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < kCst; ++i)
-                    if (i * 256 + tid < kVec) reinterpret_cast<f32x4*>(imgc)[i * 256 + tid] = __builtin_bit_cast(f32x4, cst[i]);
+            for (int m = 0; m < 4; ++m) af[m] = an[m];
+            if (G + kBAhead < KG) bq[G + kBAhead] = bsrc[(size_t)(G + kBAhead) * 256];
+        }
+        stamp(3);
+        // accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                otile[(m * 16 + (lane >> 4) * 4 + q) * kOutStride + wave * 16 + (lane & 15)] = acc[m][q];
+    } else {
+        // =============================== feeder waves ============================================
+        const int ht = tid - 256;  // 0..255
+        // A image: thread copies the float4s (row, 4*c4 + 32*j), slab j = 2 MFMA groups, of rows srow and
+        // srow+32 of the 64 params rows. Rows are only 4-byte aligned (413 floats), hence the f4u loads.
+        // k >= 400 (pose feature, template row, zero padding) is written by the tail code below, not staged.
+        const int srow = ht >> 3, c4 = ht & 7;
+        // rows past the end of a ragged last block re-read the batch's last row (valid memory, results never
+        // stored): the loads stay unconditional -- no exec-mask branch per load in the feeders' issue stream
+        const int r0 = min(img0 + srow, a.batch - 1), r1 = min(img0 + srow + 32, a.batch - 1);
+        const float* prow0 = a.params + (size_t)r0 * P;
+        const float* prow1 = a.params + (size_t)r1 * P;
+        float* adst0 = a_lds + srow * LD + 4 * c4;
+        float* adst1 = adst0 + 32 * LD;
+        auto beta4 = [&](const float* prow, int k) -> float4 {  // k + 3 < 400 guaranteed by the caller
+            if (CONTIG) {
+                const f4u v = *reinterpret_cast<const f4u*>(prow + k);
+                return float4{v.x, v.y, v.z, v.w};
             }
-            if (q == 5 && c == 1 && !(DAD3D_ABLATE & 8)) {
-                // rows of the A image past the betas: pose feature (R_j - I), the template's 1, zero padding.
-                // 16 lanes per wave, one image each; published by the chunk barriers long before chunk 12.
+            return float4{beta_at(prow, a, k), beta_at(prow, a, k + 1), beta_at(prow, a, k + 2), beta_at(prow, a, k + 3)};
+        };
+        constexpr int kSlabs = (kNumBeta + 31) / 32;  // 13 slabs hold betas (the last one half)
+        float4 s0[kSlabs], s1[kSlabs];
+#define DAD3D_LOAD_PART(p)                                                        \
+    _Pragma("unroll") for (int jj = PT::begin(p) / 2; jj < PT::begin((p) + 1) / 2 && jj < kSlabs; ++jj) { \
+        const int kk = (32 * jj + 28 < kNumBeta) ? 32 * jj + 4 * c4 : min(32 * jj + 4 * c4, kNumBeta - 4); \
+        s0[jj] = beta4(prow0, kk);                                                \
+        s1[jj] = beta4(prow1, kk);                                                \
+    }
+#define DAD3D_WRITE_PART(p)                                                       \
+    _Pragma("unroll") for (int jj = PT::begin(p) / 2; jj < PT::begin((p) + 1) / 2 && jj < kSlabs; ++jj) { \
+        if (32 * jj + 4 * c4 < kNumBeta) {                                        \
+            *reinterpret_cast<float4*>(adst0 + 32 * jj) = s0[jj];                 \
+            *reinterpret_cast<float4*>(adst1 + 32 * jj) = s1[jj];                 \
+        }                                                                         \
+    }
+        DAD3D_LOAD_PART(0)
+        DAD3D_LOAD_PART(1)
+        // pose inputs of image (16*(wave-4) + lane) for the A rows past the betas; per-vertex constants
+        PoseIn pose_in{};
+        const int trow = (wave - 4) * 16 + lane;
+        const bool tail_live = lane < 16 && img0 + trow < a.batch;
+        if (tail_live) pose_in = load_pose(a.params + (size_t)(img0 + trow) * P, a.lay);
+        float vc = 0.0f;
+        int lh = -1;
+        if (ht < kTileVerts * 8) {
+            const int v = v0 + ht / 8;
+            vc = (v < a.n_verts) ? a.weights8[(size_t)v * 8 + (ht & 7)] : 0.0f;
+        }
+        if (ht < kTileVerts && v0 + ht < a.n_verts && a.n_lmk > 0) lh = a.lmk_head[v0 + ht];
+        stamp(1);
+        DAD3D_WRITE_PART(0)
+        publish_part(0);
+        stamp(2);
+        DAD3D_LOAD_PART(2)
+        DAD3D_WRITE_PART(1)
+        publish_part(1);
+        {   // computed while the loads of part 2 are in flight; published with part 2
+                // rows of the A image past the betas: pose feature (R_j - I), the template's 1, zero padding
                 if (lane < 16) {
-                    const int row = wave * 16 + lane;
-                    float* dst = a_lds + row * LD + kNumBeta;
+                    float* dst = a_lds + trow * LD + kNumBeta;
                     float tail[L::K - kNumBeta];
 #pragma unroll
                     for (int i = 0; i < L::K - kNumBeta; ++i) tail[i] = 0.0f;
@@ -445,70 +620,65 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
                         reinterpret_cast<float4*>(dst)[i] =
                             float4{tail[4 * i], tail[4 * i + 1], tail[4 * i + 2], tail[4 * i + 3]};
                 }
-                if (tid < kTileVerts * 8) vconst[tid] = vc;
-                if (tid < kTileVerts) lmkh[tid] = lh;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                if (ht < kTileVerts * 8) vconst[ht] = vc;
+                if (ht < kTileVerts) lmkh[ht] = lh;
         }
-    }
-#undef DAD3D_ISSUE
-#undef DAD3D_COMMIT
-    stamp(3);
-
-    // accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            otile[(m * 16 + (lane >> 4) * 4 + q) * kOutStride + wave * 16 + (lane & 15)] = acc[m][q];
-
-    // ---- hand-off from the pose role, blocking path (the early look above found the block not yet published) --
-    // One lane polls the arrival counter (relaxed, agent scope) until every image of this launch has been
-    // published; the block is then fetched with sc1 loads (served by L2/memory, never a stale L1 line).
-    if (!early) {
-        if (tid == 0) {
-            int ok = 0;
+        DAD3D_WRITE_PART(2)
+        publish_part(2);
+#undef DAD3D_LOAD_PART
+#undef DAD3D_WRITE_PART
+        stamp(3);
+        // ---- hand-off from the pose role (the mma waves are still multiplying the last, largest part) ------
+        // One lane polls the arrival counter (relaxed, agent scope) until every image of this launch has been
+        // published; the block is then fetched with sc1 loads (served by L2/memory, never a stale L1 line).
+        constexpr int kVec = kBlockImages * kImgConsts / 4;  // float4s of this block's per-image constants
+        constexpr int kCst = (kVec + 255) / 256;
+        const __amdgpu_buffer_rsrc_t imgc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.imgc + (size_t)img0 * kImgConsts, 0, min(kBlockImages, a.batch - img0) * kImgConsts * (int)sizeof(float),
+            0x00020000);  // rows past the batch read as zeros (buffer bounds check)
+        // ONE poller per workgroup (240 pollers on one word already cost the memory system something; four per
+        // workgroup with a short sleep measurably slowed the pose role they were waiting for), generous sleep
+        // between polls; the other feeder waves wait on an LDS flag.
+        if (wave == 4 && lane == 0) {
+            int st = 2;
             for (unsigned spin = 0; spin < a.spin_limit; ++spin) {
                 const unsigned seen = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(seen - a.arrive_target) >= 0) {
-                    ok = 1;
+                    st = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(10);
             }
-            *handoff_ok = ok;
+            __hip_atomic_store(handoff_flag, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
-        if (*handoff_ok) {
+        while (lds_peek(handoff_flag) == 0) __builtin_amdgcn_s_sleep(4);
+        const int ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
+        if (trace && lane == 0) trace[14] = wall_clock64();
+        if (ok) {
 #pragma unroll
             for (int i = 0; i < kCst; ++i) {
-                const int idx = i * 256 + tid;
+                const int idx = i * 256 + ht;
                 if (idx < kVec) {
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, idx * 16, 0, kCacheSc1);
                     reinterpret_cast<f32x4*>(imgc)[idx] = __builtin_bit_cast(f32x4, v);
                 }
             }
         } else {
-            // time-out (the pose role's workgroups were not scheduled in time): compute the block here
-            if (tid == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float* scr = a_lds + wave * 96;  // the A image is dead by now
+            // time-out (the pose role's workgroups were not scheduled in time): this wave computes the constants
+            // of its own 16 images itself, straight into the LDS block (lane 0 writes all 84 floats of an image)
+            if (lane == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < 16; ++i) {
-                const int row = wave * 16 + i;
-                if (img0 + row < a.batch) {
-                    image_constants(a, a.params + (size_t)(img0 + row) * P, scr, lane);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    for (int e = lane; e < kImgConsts; e += 64) imgc[row * kImgConsts + e] = scr[e];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                }
+                const int row = (wave - 4) * 16 + i;
+                if (img0 + row < a.batch) image_constants<JAW_ONLY, CONTIG>(a, a.params + (size_t)(img0 + row) * P, imgc + row * kImgConsts, lane);
             }
         }
     }
-    __syncthreads();
+    __syncthreads();  // accumulator tile (mma waves) + per-image constants (feeders) are in LDS
     stamp(4);
 
-    // ---- epilogue -------------------------------------------------------------------------------------
-    // Wave w finishes images [16w, 16w+16). A lane owns ONE vertex of the tile (its skinning weights stay
-    // in registers) and walks the images three at a time: lane = 21*g + j -> vertex j, image 3*it + g.
+    // ---- epilogue (all 8 waves) -------------------------------------------------------------------------
+    // Wave w finishes images [8w, 8w+8). A lane owns ONE vertex of the tile (its skinning weights stay in
+    // registers) and walks the images three at a time: lane = 21*g + j -> vertex j, image 3*it + g.
     // Stores of one image are a contiguous run of 21 vertices.
     const int j = lane % kTileVerts, g = lane / kTileVerts;
     const int v = v0 + j;
@@ -523,11 +693,11 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
     const float zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
     const int pc = to2d ? 2 : 3;
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < 3; ++it) {
         const int li = 3 * it + g;
-        const int i = wave * 16 + li;
+        const int i = wave * 8 + li;
         const int b = img0 + i;
-        if (!(vlive && li < 16 && b < a.batch)) continue;
+        if (!(vlive && li < 8 && b < a.batch)) continue;
         const float* o = otile + i * kOutStride + 3 * j;
         const float x = o[0], y = o[1], z = o[2];  // v_posed
         const float4* c4p = reinterpret_cast<const float4*>(imgc + i * kImgConsts);
@@ -608,6 +778,7 @@ __global__ __launch_bounds__(256, 1) void flame_decode_kernel(DecodeArgs a) {
         }
     }
     stamp(5);
+    if (trace && lane == 0) trace[13] = wall_clock64();
 }
 
 size_t flame_decode_lds_bytes(int kgroups) {
@@ -624,7 +795,7 @@ static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
         attr_done = true;
     }
     const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8 * a.nbb;
-    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG>), dim3(grid), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

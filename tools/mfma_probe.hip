@@ -99,6 +99,68 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, unsigned long long* 
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// A fragments read row-major with row stride LD floats (the decode kernel's A image): per group of 16 k,
+// 4 ds_read_b128 (one per 16-image row block), lane (q,i) reads row 16m+i, columns 16G+4q..+3
+template <int LD>
+__global__ __launch_bounds__(256, 1) void probe_rowmajor(float* out, unsigned long long* cyc, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 64 * LD; i += 256) lds[i] = 1.0f + i * 1e-6f;
+    __syncthreads();
+    f32x4 acc[4] = {};
+    const float* afrag = lds + (lane & 15) * LD + 4 * (lane >> 4);
+    float b = 1.0f + lane;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        float4 af[4], an[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
+#pragma unroll
+        for (int G = 0; G < 26; ++G) {
+            if (G + 1 < 26) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[m], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = an[m];
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float r = 0;
+    for (int m = 0; m < 4; ++m) r += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int LD>
+void run_rowmajor(int blocks) {
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, blocks * 256 * 4);
+    hipMalloc(&cyc, blocks * 8);
+    hipFuncSetAttribute((const void*)&probe_rowmajor<LD>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * LD * 4);
+    const int iters = 20;
+    probe_rowmajor<LD><<<blocks, 256, 64 * LD * 4>>>(out, cyc, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[1024];
+    hipMemcpy(h, cyc, blocks * 8, hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (int i = 0; i < blocks; ++i) mean += h[i];
+    mean /= blocks;
+    printf("row-major A image, LD=%d: %.1f ticks per group of 16 MFMAs (512 = MFMA-bound)\n", LD, mean / (26.0 * iters));
+    hipFree(out);
+    hipFree(cyc);
+}
+
 template <int MODE>
 void run(const char* name, int blocks) {
     float* out;
@@ -134,6 +196,8 @@ void run(const char* name, int blocks) {
 }
 
 int main() {
+    run_rowmajor<416>(240); run_rowmajor<420>(240); run_rowmajor<424>(240); run_rowmajor<428>(240); run_rowmajor<432>(240); run_rowmajor<436>(240); run_rowmajor<440>(240); run_rowmajor<444>(240); run_rowmajor<452>(240);
+
     for (int blocks : {1, 240}) {
         run<0>("bare 16x16x4 x4 acc", blocks);
         run<1>("+ds_read_b128 2-ahead", blocks);

@@ -22,7 +22,8 @@ hm = HeadMesh(flame_model=synthetic.synthetic_flame_model(0, st), landmarks=land
 p = torch.from_numpy(synthetic.synthetic_params(batch, seed=0)).cuda()
 nbb = (batch + 63) // 64
 grid = 240 * nbb  # decode-role workgroups (the pose role is not traced)
-trace = torch.zeros((grid, 4, 32), dtype=torch.int64, device="cuda")
+n_pose = (batch + 3) // 4
+trace = torch.zeros((grid * 8 + n_pose * 4, 32), dtype=torch.int64, device="cuda")
 lib = _lib.load()
 for _ in range(20):
     hm.decode(p, to_2d=True, landmarks_px=True)
@@ -31,14 +32,34 @@ v3 = torch.empty((batch, 5023, 3), device="cuda"); pr = torch.empty((batch, 5023
 _lib.check(lib.dad3d_flame_decode(hm.flame._handle, p.data_ptr(), batch, _lib.TO_2D | dbg, v3.data_ptr(), pr.data_ptr(), None, lp.data_ptr(), None))
 torch.cuda.synchronize()
 _lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None))
-full = trace.cpu().numpy().astype(np.float64)
+allrows = trace.cpu().numpy().astype(np.float64)
+pose = allrows[grid * 8 :].reshape(n_pose, 4, 32)
+full = allrows[: grid * 8].reshape(grid, 8, 32)
 t = full[..., :6]
-t0 = t[..., 0].min()
-names = ["issue loads", "wait operands", "GEMM", "stage tile", "epilogue"]
+names = ["issue first loads", "first chunk lands", "GEMM (+staging)", "stage acc tile / hand-off", "epilogue"]
+t[:, :4, 1] = t[:, :4, 0]  # mma waves have no "loads issued" stamp
 d = np.diff(t, axis=-1)
-print(f"batch {batch}: grid {grid} blocks; ticks are s_memtime units")
-print("kernel span (first start -> last end):", t[..., 5].max() - t0)
-print("block start spread:", t[..., 0].max() - t0)
+print(f"batch {batch}: {grid} decode workgroups; ticks are s_memtime shader-clock units (one counter per XCD)")
+print("phase                        mma waves (0-3)   feeder waves (4-7)")
 for i, n in enumerate(names):
-    print(f"  {n:14s} mean {d[..., i].mean():9.1f}  min {d[..., i].min():9.1f}  max {d[..., i].max():9.1f}")
+    print(f"  {n:26s} {d[:, :4, i].mean():9.1f}         {d[:, 4:, i].mean():9.1f}")
 print("per-wave total mean", (t[..., 5] - t[..., 0]).mean())
+if full[..., 8].max() > 0:  # fine stamps of a diagnostics build (DAD3D_ABLATE & 64)
+    m = full[:, :4]
+    print("mma fine stamps (ticks since GEMM start): ", [round(float((m[..., k] - m[..., 2]).mean())) for k in range(8, 15)], " GEMM end", round(float((m[..., 3] - m[..., 2]).mean())))
+pl = pose[..., 0] > 0
+print("pose role waves: compute %.0f  store+drain %.0f  arrive %.0f ticks (mean over %d waves)" % (
+    (pose[..., 1] - pose[..., 0])[pl].mean(), (pose[..., 2] - pose[..., 1])[pl].mean(), (pose[..., 3] - pose[..., 2])[pl].mean(), pl.sum()))
+t00 = min(full[..., 12].min(), pose[..., 12][pl].min())  # 100 MHz wall clock, comparable across the chip
+us = lambda x: (x - t00) / 100.0
+print("wall clock (us after the first wave of the launch): decode waves start %.2f..%.2f, end %.2f..%.2f; pose waves start %.2f..%.2f, end %.2f..%.2f; feeders see the hand-off %.2f..%.2f" % (
+    us(full[..., 12].min()), us(full[..., 12].max()), us(full[..., 13].min()), us(full[..., 13].max()),
+    us(pose[..., 12][pl].min()), us(pose[..., 12][pl].max()), us(pose[..., 13][pl].min()), us(pose[..., 13][pl].max()),
+    us(full[:, 4:, 14].min()), us(full[:, 4:, 14].max())))
+if pose[..., 4].max() > 0:
+    print("pose fine (ticks from wave start): loads landed + Jdirs in LDS %.0f, joints done %.0f, block computed %.0f" % tuple(
+        (pose[..., k] - pose[..., 0])[pl].mean() for k in (4, 5, 1)))
+if pose[..., 7].max() > 0:
+    print("pose second pass (warm I-cache) of joints+block: %.0f ticks" % (pose[..., 7] - pose[..., 6])[pl].mean())
+if pose[..., 9].max() > 0:
+    print("  warm pass: dots %.0f, reduce+read %.0f, scalar block %.0f" % tuple((pose[..., k1] - pose[..., k0])[pl].mean() for k0, k1 in ((6, 8), (8, 9), (9, 7))))
