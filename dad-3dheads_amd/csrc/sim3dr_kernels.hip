@@ -20,6 +20,7 @@
 //     (128 KiB), lanes stride over the triangle list and ds_max_u64 their fragments, then every pixel
 //     is resolved once from the winning triangle. The z-buffer never touches HBM.
 #include <climits>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -167,72 +168,165 @@ __global__ __launch_bounds__(kRasterThreads) void raster_kernel(RasterArgs a) {
     }
     __syncthreads();
 
-    for (int f = tid; f < a.m.ntri; f += kRasterThreads) {
-        const int i0 = a.m.tri[3 * f], i1 = a.m.tri[3 * f + 1], i2 = a.m.tri[3 * f + 2];
-        const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
-        const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
-        const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1], z2 = vb[3 * i2 + 2];
-        // bounding box exactly as rasterize_kernel.cpp:246-254, then clipped to this tile
-        int bx0 = max(f2i_x86(ceilf(std_min(x0, std_min(x1, x2)))), 0);
-        int bx1 = min(f2i_x86(floorf(std_max(x0, std_max(x1, x2)))), a.w - 1);
-        int by0 = max(f2i_x86(ceilf(std_min(y0, std_min(y1, y2)))), 0);
-        int by1 = min(f2i_x86(floorf(std_max(y0, std_max(y1, y2)))), a.h - 1);
-        if (bx1 < bx0 || by1 < by0) continue;
-        bx0 = max(bx0, tx0);
-        bx1 = min(bx1, tx0 + tw - 1);
-        by0 = max(by0, ty0);
-        by1 = min(by1, ty0 + th - 1);
-        if (bx1 < bx0 || by1 < by0) continue;
-        const TriSetup ts = tri_setup(x0, y0, x1, y1, x2, y2);
+    // One pixel test of triangle (ts, z0..z2, lowkey) at (x, y): identical arithmetic whichever lane runs it.
+    auto fragment = [&](const TriSetup& ts, float z0, float z1, float z2, unsigned long long lowkey, int x, int y) {
+        float u, v;
+        tri_uv(ts, (float)x, (float)y, u, v);
+        const float w0 = 1.0f - u - v;
+        const bool inside = (MODE == 0) ? (u > 0.0f && v > 0.0f && w0 > 0.0f) : (u >= 0.0f && v >= 0.0f && (u + v < 1.0f));
+        if (!inside) return;
+        const float z = w0 * z0 + v * z1 + u * z2;
+        if (z != z) return;  // NaN never passes `>`
+        const unsigned long long key = ((unsigned long long)depth_order(z) << 32) | lowkey;
+        // fire-and-forget ds_max_u64: no returned value, so the wave never waits on the LDS round trip
+        (void)__hip_atomic_fetch_max(&keys[(y - ty0) * kTile + (x - tx0)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // Lanes stride over the triangle list. Small boxes are scanned by the owning lane; a box of more than
+    // kBigBox pixels (a few percent of the triangles, about half of all pixel tests on a head mesh) is handed to
+    // the whole wave -- its setup is broadcast with v_readlane and the 64 lanes share the box -- otherwise one
+    // lane with an 800-pixel box would hold 63 idle lanes for thousands of cycles.
+    constexpr int kBigBox = 32;
+    const int lane = tid & 63;
+    for (int f0 = tid - lane; f0 < a.m.ntri; f0 += kRasterThreads) {  // f0 is wave-uniform: no lane leaves early
+        const int f = f0 + lane;
+        bool valid = f < a.m.ntri;
+        int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        TriSetup ts{};
+        if (valid) {
+            const int i0 = a.m.tri[3 * f], i1 = a.m.tri[3 * f + 1], i2 = a.m.tri[3 * f + 2];
+            const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1];
+            const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1];
+            const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1];
+            z0 = vb[3 * i0 + 2], z1 = vb[3 * i1 + 2], z2 = vb[3 * i2 + 2];
+            // bounding box exactly as rasterize_kernel.cpp:246-254, then clipped to this tile
+            bx0 = max(f2i_x86(ceilf(std_min(x0, std_min(x1, x2)))), 0);
+            bx1 = min(f2i_x86(floorf(std_max(x0, std_max(x1, x2)))), a.w - 1);
+            by0 = max(f2i_x86(ceilf(std_min(y0, std_min(y1, y2)))), 0);
+            by1 = min(f2i_x86(floorf(std_max(y0, std_max(y1, y2)))), a.h - 1);
+            valid = !(bx1 < bx0 || by1 < by0);
+            bx0 = max(bx0, tx0);
+            bx1 = min(bx1, tx0 + tw - 1);
+            by0 = max(by0, ty0);
+            by1 = min(by1, ty0 + th - 1);
+            valid = valid && !(bx1 < bx0 || by1 < by0);
+            if (valid) ts = tri_setup(x0, y0, x1, y1, x2, y2);
+        }
         const unsigned long long lowkey = 0xFFFFFFFEu - (unsigned)f;
-        for (int y = by0; y <= by1; ++y)
-            for (int x = bx0; x <= bx1; ++x) {
-                float u, v;
-                tri_uv(ts, (float)x, (float)y, u, v);
-                const float w0 = 1.0f - u - v;
-                const bool inside = (MODE == 0) ? (u > 0.0f && v > 0.0f && w0 > 0.0f)
-                                                : (u >= 0.0f && v >= 0.0f && (u + v < 1.0f));
-                if (!inside) continue;
-                const float z = w0 * z0 + v * z1 + u * z2;
-                if (z != z) continue;  // NaN never passes `>`
-                const unsigned long long key = ((unsigned long long)depth_order(z) << 32) | lowkey;
-                unsigned long long* slot = &keys[(y - ty0) * kTile + (x - tx0)];
-                if (key > *slot) atomicMax(slot, key);
-            }
+        const bool big = valid && (bx1 - bx0 + 1) * (by1 - by0 + 1) > kBigBox;
+        if (valid && !big)
+            for (int y = by0; y <= by1; ++y)
+                for (int x = bx0; x <= bx1; ++x) fragment(ts, z0, z1, z2, lowkey, x, y);
+        unsigned long long pending = __ballot(big);
+        while (pending) {
+            const int src = __builtin_ctzll(pending);
+            pending &= pending - 1;
+            auto bi = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
+            auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+            TriSetup t2;
+            t2.x0 = bf(ts.x0), t2.y0 = bf(ts.y0), t2.ax = bf(ts.ax), t2.ay = bf(ts.ay), t2.bx = bf(ts.bx), t2.by = bf(ts.by);
+            t2.d00 = bf(ts.d00), t2.d01 = bf(ts.d01), t2.d11 = bf(ts.d11), t2.inv = bf(ts.inv);
+            const float s0 = bf(z0), s1 = bf(z1), s2 = bf(z2);
+            const int cx0 = bi(bx0), cx1 = bi(bx1), cy0 = bi(by0), cy1 = bi(by1);
+            const unsigned long long lk = 0xFFFFFFFEu - (unsigned)(f0 + src);
+            // lanes tile the box as lw x (64/lw), lw = the power of two covering min(width, 64)
+            const int bw = cx1 - cx0 + 1;
+            const int sh = bw > 32 ? 6 : bw > 16 ? 5 : bw > 8 ? 4 : 3;
+            const int lx = lane & ((1 << sh) - 1), ly = lane >> sh;
+            for (int y = cy0 + ly; y <= cy1; y += 64 >> sh)
+                for (int x = cx0 + lx; x <= cx1; x += 1 << sh) fragment(t2, s0, s1, s2, lk, x, y);
+        }
     }
     __syncthreads();
 
-    for (int p = tid; p < tw * th; p += kRasterThreads) {
-        const int ly = p / tw, lx = p - ly * tw;
-        const unsigned low = (unsigned)keys[ly * kTile + lx];
-        if (low == kNoTri) continue;  // nothing beat the incoming depth: pixel untouched
-        const int f = (int)(0xFFFFFFFEu - low);
-        const int gx = tx0 + lx, gy = ty0 + ly;
-        const int i0 = a.m.tri[3 * f], i1 = a.m.tri[3 * f + 1], i2 = a.m.tri[3 * f + 2];
-        const TriSetup ts = tri_setup(vb[3 * i0], vb[3 * i0 + 1], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i2], vb[3 * i2 + 1]);
-        float u, v;
-        tri_uv(ts, (float)gx, (float)gy, u, v);
-        const float w0 = 1.0f - u - v;
-        const float z = w0 * vb[3 * i0 + 2] + v * vb[3 * i1 + 2] + u * vb[3 * i2 + 2];
-        const size_t pix = (size_t)gy * a.w + gx;
-        if (depth_b) depth_b[pix] = z;
-        if (MODE == 0) {
-            const float* cb = a.colors + b * a.m.nver * a.c;
-            const int row = a.reverse ? (a.h - 1 - gy) : gy;
-            uint8_t* px = a.image + ((b * a.h + row) * a.w + gx) * a.c;
-            for (int k = 0; k < a.c; ++k) {
-                const float col = w0 * cb[a.c * i0 + k] + v * cb[a.c * i1 + k] + u * cb[a.c * i2 + k];
-                // (unsigned char)((1 - alpha) * old + alpha * 255 * col) with alpha == 1
-                px[k] = (uint8_t)(f2i_x86(0.0f * (float)px[k] + 255.0f * col) & 0xff);
+    // Resolve: every pixel is shaded once from its winning triangle. A thread owns four horizontally adjacent
+    // pixels: their dependent gathers (triangle -> vertices -> colours) overlap, and when the row pitch allows it
+    // the 4*c colour bytes are merged into the background as whole dwords (byte stores are read-modify-writes in
+    // L2: 3 loads + 3 stores per pixel made this pass the longest of the kernel).
+    constexpr int NB = 4;
+    const float* cb = (MODE == 0) ? a.colors + b * a.m.nver * a.c : nullptr;
+    const int qw = (tw + NB - 1) / NB;  // pixel quads per tile row
+    // C = compile-time channel count of the packed path (3: RGB, 4: RGBA), 0 = any count, bytewise
+    auto resolve = [&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    const int nc = C ? C : a.c;
+    const bool packed = MODE == 0 && C != 0;
+    for (int q = tid; q < qw * th; q += kRasterThreads) {
+        const int ly = q / qw, lx0 = (q - ly * qw) * NB;
+        const int gy = ty0 + ly;
+        int f[NB], i0[NB], i1[NB], i2[NB];
+        bool hit[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const unsigned low = (lx0 + k < tw) ? (unsigned)keys[ly * kTile + lx0 + k] : kNoTri;
+            hit[k] = low != kNoTri;  // kNoTri: nothing beat the incoming depth, the pixel stays untouched
+            f[k] = hit[k] ? (int)(0xFFFFFFFEu - low) : 0;
+        }
+        if (!(hit[0] || hit[1] || hit[2] || hit[3])) continue;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
+        float vx[NB][9];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vx[k][c] = vb[3 * i0[k] + c], vx[k][3 + c] = vb[3 * i1[k] + c], vx[k][6 + c] = vb[3 * i2[k] + c];
+        const int row = (MODE == 0 && a.reverse) ? (a.h - 1 - gy) : gy;
+        unsigned char bytes[C ? 4 * C : 4];
+        unsigned* quad = nullptr;
+        if (packed) {
+            quad = reinterpret_cast<unsigned*>(a.image + ((b * a.h + row) * a.w + tx0 + lx0) * nc);
+#pragma unroll
+            for (int d = 0; d < C; ++d) {
+                const unsigned wv = quad[d];
+                bytes[4 * d] = wv & 0xff, bytes[4 * d + 1] = (wv >> 8) & 0xff, bytes[4 * d + 2] = (wv >> 16) & 0xff, bytes[4 * d + 3] = wv >> 24;
             }
-        } else {
-            a.tri_buf[b * a.h * a.w + pix] = f;
-            float* bw = a.bary + (b * a.h * a.w + pix) * 3;
-            bw[0] = w0;
-            bw[1] = v;
-            bw[2] = u;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (!hit[k]) continue;
+            const int gx = tx0 + lx0 + k;
+            const TriSetup ts = tri_setup(vx[k][0], vx[k][1], vx[k][3], vx[k][4], vx[k][6], vx[k][7]);
+            float u, v;
+            tri_uv(ts, (float)gx, (float)gy, u, v);
+            const float w0 = 1.0f - u - v;
+            const float z = w0 * vx[k][2] + v * vx[k][5] + u * vx[k][8];
+            const size_t pix = (size_t)gy * a.w + gx;
+            if (depth_b) depth_b[pix] = z;
+            if (MODE == 0) {
+                uint8_t* px = a.image + ((b * a.h + row) * a.w + gx) * nc;
+                // (unsigned char)((1 - alpha) * old + alpha * 255 * col) with alpha == 1
+                if (packed) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const float col = w0 * cb[C * i0[k] + ch] + v * cb[C * i1[k] + ch] + u * cb[C * i2[k] + ch];
+                        unsigned char& o = bytes[k * C + ch];
+                        o = (unsigned char)(f2i_x86(0.0f * (float)o + 255.0f * col) & 0xff);
+                    }
+                } else {
+                    for (int ch = 0; ch < nc; ++ch) {
+                        const float col = w0 * cb[nc * i0[k] + ch] + v * cb[nc * i1[k] + ch] + u * cb[nc * i2[k] + ch];
+                        px[ch] = (uint8_t)(f2i_x86(0.0f * (float)px[ch] + 255.0f * col) & 0xff);
+                    }
+                }
+            } else {
+                a.tri_buf[b * a.h * a.w + pix] = f[k];
+                float* bw = a.bary + (b * a.h * a.w + pix) * 3;
+                bw[0] = w0;
+                bw[1] = v;
+                bw[2] = u;
+            }
+        }
+        if (packed) {
+#pragma unroll
+            for (int d = 0; d < C; ++d)
+                quad[d] = (unsigned)bytes[4 * d] | ((unsigned)bytes[4 * d + 1] << 8) | ((unsigned)bytes[4 * d + 2] << 16) | ((unsigned)bytes[4 * d + 3] << 24);
         }
     }
+    };
+    const bool can_pack = MODE == 0 && (a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.image) & 3) == 0;
+    if (can_pack && a.c == 3) resolve(std::integral_constant<int, 3>{});
+    else if (can_pack && a.c == 4) resolve(std::integral_constant<int, 4>{});
+    else resolve(std::integral_constant<int, 0>{});
 }
 
 // ------------------------------------------------------------------------------------------------
