@@ -80,6 +80,18 @@ def cpu_baseline(model, lmk_idx, budget_s: float = 15.0):
     }
 
 
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/*pmc*.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, KB units, FETCH doubled per MI355X_MICROARCH.md). PMC
+    cannot be collected inside this process; null when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,15 +159,14 @@ def main() -> None:
         elapsed = float(t.item())
 
     # dominant-kernel duration: the same K steps again, the run of back-to-back fused-decode launches bracketed
-    # by two hipEvents on the launch stream (a separate region so the event records do not perturb `value`)
-    _lib.check(lib.dad3d_flame_profile_enable(handle, 1))
-    for _ in range(args.steps):
-        step()
+    # by two hipEvents on the launch stream (one kernel per step, so elapsed / K is its average duration + gap)
     import ctypes as C
 
+    _lib.check(lib.dad3d_flame_profile_begin(handle, stream))
+    for _ in range(args.steps):
+        step()
     tot, cnt = C.c_double(), C.c_int()
-    _lib.check(lib.dad3d_flame_profile_read(handle, C.byref(tot), C.byref(cnt)))
-    _lib.check(lib.dad3d_flame_profile_enable(handle, 0))
+    _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     kern_s = tot.value / max(cnt.value, 1) * 1e-3
 
     # sanity: the timed path produced the oracle's answer (cheap spot check on rank 0, outside the timed region)
@@ -194,7 +205,7 @@ def main() -> None:
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": flops / kern_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(),
                 "kernel_us": kern_s * 1e6,
                 "algorithmic_flop_per_launch": flops,
                 "algorithmic_bytes_per_launch": alg_bytes,

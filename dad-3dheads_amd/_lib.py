@@ -73,8 +73,8 @@ SIGNATURES = {
     "dad3d_flame_decode": (_I, [_P, _P, _I, _U, _P, _P, _P, _P, _P]),
     "dad3d_flame_decode_host": (_I, [_P, _P, _I, _U, _P, _P, _P, _P]),
     "dad3d_flame_readjust_params": (_I, [_P, _P, _I, _P, _F, _F, _F, _P]),
-    "dad3d_flame_profile_enable": (_I, [_P, _I]),
-    "dad3d_flame_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I)]),
+    "dad3d_flame_profile_begin": (_I, [_P, _P]),
+    "dad3d_flame_profile_end": (_I, [_P, _P, C.POINTER(C.c_double), C.POINTER(_I)]),
     "dad3d_flame_handoff_timeouts": (_I, [_P, C.POINTER(C.c_uint)]),
     "dad3d_flame_debug_trace": (_I, [_P, _P]),
     "dad3d_mesh_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),

@@ -285,20 +285,11 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     da.image_size = h->image_size;
     da.flags = flags;
     dad3d_status st;
-    if (h->profiling && h->prof_launches == 0) {
-        if (!h->ev_first) {
-            DAD3D_HIP_TRY(hipEventCreate(&h->ev_first));
-            DAD3D_HIP_TRY(hipEventCreate(&h->ev_last));
-        }
-        DAD3D_HIP_TRY(hipEventRecord(h->ev_first, s));
-    }
+
     st = launch_flame_decode(da, s);
     if (st) return st;
     h->arrive_total = da.arrive_target;  // committed only once the launch was accepted
-    if (h->profiling) {
-        DAD3D_HIP_TRY(hipEventRecord(h->ev_last, s));  // re-recorded after every launch: the last one stands
-        ++h->prof_launches;
-    }
+    if (h->profiling) ++h->prof_launches;
     return DAD3D_OK;
 }
 
@@ -363,25 +354,30 @@ dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_
     return DAD3D_OK;
 }
 
-dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on) {
+dad3d_status dad3d_flame_profile_begin(dad3d_flame* h, void* stream) {
     DAD3D_REQUIRE(h, "null handle");
-    h->profiling = on != 0;
+    DeviceGuard guard(h->device);
+    if (!h->ev_first) {
+        DAD3D_HIP_TRY(hipEventCreate(&h->ev_first));
+        DAD3D_HIP_TRY(hipEventCreate(&h->ev_last));
+    }
+    h->profiling = true;
     h->prof_launches = 0;
+    DAD3D_HIP_TRY(hipEventRecord(h->ev_first, static_cast<hipStream_t>(stream)));
     return DAD3D_OK;
 }
 
-dad3d_status dad3d_flame_profile_read(dad3d_flame* h, double* total_ms, int* launches) {
+dad3d_status dad3d_flame_profile_end(dad3d_flame* h, void* stream, double* total_ms, int* launches) {
     DAD3D_REQUIRE(h && total_ms && launches, "null argument");
+    DAD3D_REQUIRE(h->profiling, "dad3d_flame_profile_end without dad3d_flame_profile_begin");
     DeviceGuard guard(h->device);
-    *total_ms = 0.0;
+    DAD3D_HIP_TRY(hipEventRecord(h->ev_last, static_cast<hipStream_t>(stream)));
+    DAD3D_HIP_TRY(hipEventSynchronize(h->ev_last));
+    float ms = 0.f;
+    DAD3D_HIP_TRY(hipEventElapsedTime(&ms, h->ev_first, h->ev_last));
+    *total_ms = ms;
     *launches = h->prof_launches;
-    if (h->prof_launches > 0) {
-        float ms = 0.f;
-        DAD3D_HIP_TRY(hipEventSynchronize(h->ev_last));
-        DAD3D_HIP_TRY(hipEventElapsedTime(&ms, h->ev_first, h->ev_last));
-        *total_ms = ms;
-    }
-    h->prof_launches = 0;
+    h->profiling = false;
     return DAD3D_OK;
 }
 

@@ -106,13 +106,12 @@ dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, u
 dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batch, const float* pads_scale,
                                          float pad_left, float pad_top, float scale, void* stream);
 
-/* Timing aid for bench.py: while enabled, the run of decode launches issued back to back on one stream is
- * bracketed by two hipEvents ON THAT STREAM (first one before the first launch, second re-recorded after
- * every launch). `_read` synchronises and returns the elapsed milliseconds from the first launch's start
- * to the last launch's end plus the launch count, then resets. With one fused kernel per decode,
+/* Timing aid for bench.py: `_begin` records a hipEvent on `stream`, `_end` records a second one on the same
+ * stream, synchronises on it and returns the elapsed milliseconds and the number of decode launches issued
+ * through this handle in between. With one fused kernel per decode and launches issued back to back,
  * total_ms / launches is that kernel's average duration including the inter-launch gap. */
-dad3d_status dad3d_flame_profile_enable(dad3d_flame* h, int on);
-dad3d_status dad3d_flame_profile_read(dad3d_flame* h, double* total_ms, int* launches);
+dad3d_status dad3d_flame_profile_begin(dad3d_flame* h, void* stream);
+dad3d_status dad3d_flame_profile_end(dad3d_flame* h, void* stream, double* total_ms, int* launches);
 /* How many decode workgroups ever gave up waiting for the pose role's hand-off and recomputed the per-image
  * constants themselves (still correct, slower). Expected 0; synchronises the device. */
 dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
