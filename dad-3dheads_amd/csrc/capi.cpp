@@ -392,6 +392,27 @@ struct dad3d_mesh {
     int *d_tri = nullptr, *d_adj_ptr = nullptr, *d_adj_face = nullptr;
     float* d_scratch = nullptr;
     int scratch_batch = 0;
+    unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_mesh_debug_trace)
+    void* d_raster = nullptr;  // per-image triangle boxes + corner planes, grown on demand (one stream at a time)
+    size_t raster_bytes = 0;
+    int raster_batch = 0, raster_h = 0, raster_w = 0;
+    // The scratch layout depends on (batch, h, w): a change of shape re-zeroes the tile counters in stream order.
+    dad3d_status raster_scratch(int batch, int h, int w, hipStream_t s) {
+        if (batch == raster_batch && h == raster_h && w == raster_w) return DAD3D_OK;
+        const size_t need = raster_scratch_bytes(dev(), batch, h, w);
+        if (need > raster_bytes) {
+            DAD3D_HIP_TRY(hipDeviceSynchronize());
+            if (d_raster) (void)hipFree(d_raster);
+            d_raster = nullptr;
+            raster_bytes = 0;
+            raster_batch = 0;
+            DAD3D_HIP_TRY(hipMalloc(&d_raster, need));
+            raster_bytes = need;
+        }
+        if (dad3d_status st = raster_scratch_init(dev(), d_raster, batch, h, w, s)) return st;
+        raster_batch = batch, raster_h = h, raster_w = w;
+        return DAD3D_OK;
+    }
     MeshDev dev() const { return MeshDev{d_tri, d_adj_ptr, d_adj_face, ntri, nver}; }
 };
 
@@ -429,7 +450,7 @@ dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int devic
 void dad3d_mesh_destroy(dad3d_mesh* m) {
     if (!m) return;
     DeviceGuard guard(m->device);
-    for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_scratch})
+    for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_scratch, m->d_raster})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -474,7 +495,8 @@ dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* ve
     DAD3D_REQUIRE(image && (vertices || m->ntri == 0) && (colors || m->ntri == 0 || c == 0),
                   "dad3d_mesh_rasterize: null buffer");
     DeviceGuard guard(m->device);
-    return launch_rasterize(m->dev(), image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse, 0,
+    if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
+    return launch_rasterize(m->dev(), m->d_raster, m->d_trace, image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse, 0,
                             static_cast<hipStream_t>(stream));
 }
 
@@ -484,8 +506,15 @@ dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices
     if (batch == 0 || h == 0 || w == 0) return DAD3D_OK;
     DAD3D_REQUIRE(depth && tri_buf && bary && (vertices || m->ntri == 0), "dad3d_mesh_rasterize_triangles: null buffer");
     DeviceGuard guard(m->device);
-    return launch_rasterize(m->dev(), nullptr, vertices, nullptr, depth, tri_buf, bary, batch, h, w, 3, 0, 1,
+    if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
+    return launch_rasterize(m->dev(), m->d_raster, m->d_trace, nullptr, vertices, nullptr, depth, tri_buf, bary, batch, h, w, 3, 0, 1,
                             static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer) {
+    DAD3D_REQUIRE(m, "null handle");
+    m->d_trace = device_buffer;
+    return DAD3D_OK;
 }
 
 dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,

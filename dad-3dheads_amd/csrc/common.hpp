@@ -118,9 +118,13 @@ dad3d_status launch_ver_normal(const MeshDev& m, float* ver_normal, const float*
                                unsigned flags, hipStream_t s);
 dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float* vertices, int batch, unsigned flags,
                                hipStream_t s);
-dad3d_status launch_rasterize(const MeshDev& m, uint8_t* image, const float* vertices, const float* colors,
-                              float* depth, int32_t* tri_buf, float* bary, int batch, int h, int w, int c,
-                              int reverse, int mode, hipStream_t s);
+// scratch: raster_scratch_bytes(..) bytes of device memory (per-image triangle boxes, setup planes, per-tile
+// triangle lists), zeroed once with raster_scratch_init before its first use
+size_t raster_scratch_bytes(const MeshDev& m, int batch, int h, int w);
+dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int h, int w, hipStream_t s);
+dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image, const float* vertices,
+                              const float* colors, float* depth, int32_t* tri_buf, float* bary, int batch, int h,
+                              int w, int c, int reverse, int mode, hipStream_t s);
 dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals, int batch,
                           const dad3d_light& cfg, float* scratch, hipStream_t s);
 

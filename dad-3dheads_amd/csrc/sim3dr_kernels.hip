@@ -19,6 +19,7 @@
 //     (orderable(depth) << 32 | ~tri): one workgroup owns a 128x128 screen tile whose keys live in LDS
 //     (128 KiB), lanes stride over the triangle list and ds_max_u64 their fragments, then every pixel
 //     is resolved once from the winning triangle. The z-buffer never touches HBM.
+#include <algorithm>
 #include <climits>
 #include <type_traits>
 
@@ -129,9 +130,44 @@ __global__ void ver_normal_kernel(MeshDev m, float* ver_normal, const float* src
 // ------------------------------------------------------------------------------------------------
 // rasterisation
 // ------------------------------------------------------------------------------------------------
-constexpr int kTile = 128;          // screen tile edge; 128*128 u64 keys = 128 KiB of the 160 KiB LDS
-constexpr int kRasterThreads = 1024;
+// Three launches per batch:
+//   tri_geometry_kernel  one lane per triangle, once per image. The vertices of the image are staged in LDS
+//                        (60 KB for FLAME), so the corner coordinates are LDS gathers instead of scattered global
+//                        loads. It writes one 64-byte record per triangle -- the screen bounding box exactly as
+//                        rasterize_kernel.cpp:246-254 computes it, the pixel-independent half of get_point_weight
+//                        (TriSetup) and the corner depths -- and appends the triangle to the list of every 64x64
+//                        screen tile its box touches (LDS counters, one global atomic per block and tile).
+//   raster_queue_kernel  one block: turns the tile counters into a work queue, heaviest first; a tile with more
+//                        than kSplit1 (kSplit2) triangles becomes 4 (16) items of 32x32 (16x16) pixels, so no item
+//                        is much heavier than the rest (eyes, lips and ears of a head mesh put 3000+ triangles
+//                        into one tile while most tiles hold a few hundred).
+//   raster_kernel        persistent workgroups pull items. Per item, keys in LDS: (A) counting-sort the tile list by
+//                        box area into 9 classes; a class-c triangle gets 2^max(c-2,0) lanes, so every lane of a
+//                        wave has at most 8 pixel tests to do whatever the triangle size (one-lane-per-triangle
+//                        left most lanes idle). (B) the lanes ds_max_u64 their fragments. (C) every pixel is shaded
+//                        once from the record of its winning triangle and merged into the image as whole dwords.
+// The z-buffer never touches HBM; list and queue order are irrelevant to the result because the key maximum is
+// order-independent.
+constexpr int kTile = 64;            // screen tile edge; 64*64 u64 keys = 32 KiB
+constexpr int kTileShift = 6;
+constexpr int kRasterThreads = 512;
+constexpr int kRasterWaves = kRasterThreads / 64;
+constexpr int kListCap = 4096;       // list entries sorted per round (u32 ids, 16 KiB)
+constexpr int kListPerThread = kListCap / kRasterThreads;
+constexpr int kClasses = 12;         // box area <=2, <=4, <=8, <=16, ... <=4096 (= a whole tile)
+constexpr int kSpread = 16;          // copies of every class counter: 64 lanes hit 16 addresses instead of one
+constexpr int kRecF4 = 4;            // one 64-byte record per (image, triangle): x0 y0 ax ay | bx by d00 d01 |
+                                     // d11 inv z0 z1 | z2 box.x box.y 0  -- exactly one cache line, read as 4 x b128
+constexpr int kGeoThreads = 1024;
+constexpr int kGeoPerThread = 3;
+constexpr int kGeoTrisPerBlock = kGeoThreads * kGeoPerThread;
+constexpr int kMaxTiles = 4096;      // LDS counters of the geometry kernel
+constexpr unsigned kSplit1 = 40000, kSplit2 = 160000;  // tile cost (pixel tests + 8 per triangle) above which a tile
+                                                        // is split 2x2 / 4x4
+constexpr int kMaxSubs = 16;
+constexpr int kQueueBuckets = 64;
 constexpr unsigned kNoTri = 0xFFFFFFFFu;
+constexpr unsigned kIdMask = 0x0FFFFFFFu;  // list entry = triangle | class << 28
 
 __device__ __forceinline__ unsigned depth_order(float z) {  // monotone float -> uint; NaN sorts on top
     if (z != z) return 0xFFFFFFFFu;
@@ -139,194 +175,546 @@ __device__ __forceinline__ unsigned depth_order(float z) {  // monotone float ->
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// 0: <=2, 1: <=4, 2: <=8, ... 11: <=4096 pixels. A class-c triangle gets 2^max(c-2,0) lanes (up to 8 waves' worth):
+// no lane has more than 8 pixel tests per triangle.
+__device__ __forceinline__ int area_class(int area) {
+    return min(max(31 - __clz(max(area - 1, 1)) - (area <= 2 ? 1 : 0), 0), kClasses - 1);
+}
+
+struct RasterScratch {
+    float4* rec;        // [B][ntri][4]   TriSetup, corner depths, screen box (x0 | x1 << 16, y0 | y1 << 16; empty =
+                        //                (1,0),(1,0)) of a triangle
+    unsigned* counts;   // [2][B * ntiles]  triangles in a tile list, then the sum of their box areas inside the tile;
+                        //                  zero between launches (the queue kernel resets them)
+    unsigned* lists;    // [B * ntiles][ntri]   triangle | area class within the tile << 28
+    unsigned* qhdr;     // [0] work items in the queue  [1] next item to hand out
+    uint2* queue;       // [16 * B * ntiles]  .x = tile index | split level << 24 | part << 26, .y = list length
+    int tiles_x, tiles_y;
+};
+
+template <bool LDS_VERTS>
+__global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, const float* vertices, RasterScratch sc,
+                                                                   int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) float lds_v[];
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const int ntiles = sc.tiles_x * sc.tiles_y;
+    const float* vb = vertices + b * m.nver * 3;
+    // lv[e] == vb[e]; the LDS image is shifted so that the 16-byte aligned part of vb moves as float4
+    const int n = LDS_VERTS ? m.nver * 3 : 0;
+    const int head = LDS_VERTS ? min(n, (int)(((16 - (reinterpret_cast<uintptr_t>(vb) & 15)) & 15) >> 2)) : 0;
+    float* lv = lds_v + ((4 - head) & 3);
+    unsigned* cnt = reinterpret_cast<unsigned*>(lds_v + ((n + 7) & ~3));  // [ntiles] block-local counts, then cursors
+    unsigned* asum = cnt + ntiles;                                        // [ntiles] block-local box area sums
+    for (int t = tid; t < 2 * ntiles; t += kGeoThreads) cnt[t] = 0;
+    if (LDS_VERTS) {
+        const int n4 = (n - head) >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(vb + head);
+        float4* l4 = reinterpret_cast<float4*>(lv + head);
+        for (int i = tid; i < n4; i += kGeoThreads) l4[i] = g4[i];
+        if (tid < head) lv[tid] = vb[tid];
+        const int tail0 = head + 4 * n4;
+        if (tid < n - tail0) lv[tail0 + tid] = vb[tail0 + tid];
+    }
+    __syncthreads();
+    auto coord = [&](int e) { return LDS_VERTS ? lv[e] : vb[e]; };
+    const size_t nt = m.ntri;
+    uint2 box[kGeoPerThread];
+#pragma unroll
+    for (int k = 0; k < kGeoPerThread; ++k) {
+        const int f = blockIdx.x * kGeoTrisPerBlock + k * kGeoThreads + tid;
+        box[k] = make_uint2(1u, 1u);  // empty
+        if (f >= m.ntri) continue;
+        const int i0 = m.tri[3 * f], i1 = m.tri[3 * f + 1], i2 = m.tri[3 * f + 2];
+        const float x0 = coord(3 * i0), y0 = coord(3 * i0 + 1), z0 = coord(3 * i0 + 2);
+        const float x1 = coord(3 * i1), y1 = coord(3 * i1 + 1), z1 = coord(3 * i1 + 2);
+        const float x2 = coord(3 * i2), y2 = coord(3 * i2 + 1), z2 = coord(3 * i2 + 2);
+        // bounding box exactly as rasterize_kernel.cpp:246-254
+        int bx0 = max(f2i_x86(ceilf(std_min(x0, std_min(x1, x2)))), 0);
+        int bx1 = min(f2i_x86(floorf(std_max(x0, std_max(x1, x2)))), w - 1);
+        int by0 = max(f2i_x86(ceilf(std_min(y0, std_min(y1, y2)))), 0);
+        int by1 = min(f2i_x86(floorf(std_max(y0, std_max(y1, y2)))), h - 1);
+        if (bx1 < bx0 || by1 < by0) bx0 = by0 = 1, bx1 = by1 = 0;  // `continue` in the reference: empty box
+        box[k] = make_uint2((unsigned)bx0 | ((unsigned)bx1 << 16), (unsigned)by0 | ((unsigned)by1 << 16));
+        const TriSetup ts = tri_setup(x0, y0, x1, y1, x2, y2);
+        float4* rp = sc.rec + (b * nt + f) * kRecF4;
+        rp[0] = make_float4(ts.x0, ts.y0, ts.ax, ts.ay);
+        rp[1] = make_float4(ts.bx, ts.by, ts.d00, ts.d01);
+        rp[2] = make_float4(ts.d11, ts.inv, z0, z1);
+        rp[3] = make_float4(z2, __uint_as_float(box[k].x), __uint_as_float(box[k].y), 0.0f);
+        if (bx0 <= bx1)
+            for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
+                for (int tx = bx0 >> kTileShift; tx <= bx1 >> kTileShift; ++tx) {
+                    const int cw = min(bx1, tx * kTile + kTile - 1) - max(bx0, tx * kTile) + 1;
+                    const int ch = min(by1, ty * kTile + kTile - 1) - max(by0, ty * kTile) + 1;
+                    atomicAdd(&cnt[ty * sc.tiles_x + tx], 1u);
+                    atomicAdd(&asum[ty * sc.tiles_x + tx], (unsigned)(cw * ch));
+                }
+    }
+    __syncthreads();
+    // reserve this block's share of every tile list; cnt[] becomes the write cursor
+    for (int t = tid; t < ntiles; t += kGeoThreads) {
+        const unsigned c = cnt[t];
+        cnt[t] = c ? atomicAdd(&sc.counts[b * ntiles + t], c) : 0u;
+        if (c) atomicAdd(&sc.counts[(gridDim.y + b) * ntiles + t], asum[t]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGeoPerThread; ++k) {
+        const int f = blockIdx.x * kGeoTrisPerBlock + k * kGeoThreads + tid;
+        const int bx0 = box[k].x & 0xffff, bx1 = box[k].x >> 16, by0 = box[k].y & 0xffff, by1 = box[k].y >> 16;
+        if (bx0 > bx1) continue;  // empty box: in no list
+        for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
+            for (int tx = bx0 >> kTileShift; tx <= bx1 >> kTileShift; ++tx) {
+                const int t = ty * sc.tiles_x + tx;
+                const int cw = min(bx1, tx * kTile + kTile - 1) - max(bx0, tx * kTile) + 1;
+                const int ch = min(by1, ty * kTile + kTile - 1) - max(by0, ty * kTile) + 1;
+                sc.lists[(b * ntiles + t) * nt + atomicAdd(&cnt[t], 1u)] = (unsigned)f | ((unsigned)area_class(cw * ch) << 28);
+            }
+    }
+}
+
+// Work queue, heaviest items first (bucket sort on list length / parts); resets the tile counters.
+__global__ __launch_bounds__(1024) void raster_queue_kernel(RasterScratch sc, int n_lists) {
+    __shared__ unsigned hist[kQueueBuckets];
+    const int tid = threadIdx.x;
+    if (tid < kQueueBuckets) hist[tid] = 0;
+    __syncthreads();
+    // cost of a tile ~ pixel tests (box areas) + a per-triangle overhead; a part costs about a quarter / sixteenth
+    auto plan = [&](unsigned c, unsigned area, int& level, int& bucket) {
+        const unsigned cost = area + 8 * c;
+        level = cost > kSplit2 ? 2 : cost > kSplit1 ? 1 : 0;
+        bucket = min((int)((cost >> (2 * level)) >> 10), kQueueBuckets - 1);
+    };
+    for (int i = tid; i < n_lists; i += 1024) {
+        const unsigned c = sc.counts[i];
+        if (!c) continue;
+        int level, bucket;
+        plan(c, sc.counts[n_lists + i], level, bucket);
+        atomicAdd(&hist[bucket], 1u << (2 * level));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int k = kQueueBuckets - 1; k >= 0; --k) {
+            const unsigned n = hist[k];
+            hist[k] = run;  // becomes the write cursor of the bucket
+            run += n;
+        }
+        sc.qhdr[0] = run;
+        sc.qhdr[1] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_lists; i += 1024) {
+        const unsigned c = sc.counts[i];
+        if (!c) continue;
+        int level, bucket;
+        plan(c, sc.counts[n_lists + i], level, bucket);
+        sc.counts[i] = 0, sc.counts[n_lists + i] = 0;  // leave the list empty for the next launch
+        const unsigned parts = 1u << (2 * level);
+        const unsigned pos = atomicAdd(&hist[bucket], parts);
+        for (unsigned p = 0; p < parts; ++p) sc.queue[pos + p] = make_uint2((unsigned)i | ((unsigned)level << 24) | (p << 26), c);
+    }
+}
+
 struct RasterArgs {
     MeshDev m;
+    RasterScratch sc;
     uint8_t* image;
-    const float* vertices;
     const float* colors;
     float* depth;
     int32_t* tri_buf;
     float* bary;
-    int h, w, c, reverse, tiles_x;
+    unsigned long long* trace;  // diagnostics: [work items][8 waves][16] wall-clock stamps and counters, or null
+    int h, w, c, reverse;
 };
 
-// MODE 0: _rasterize (strictly-interior test, colour output)   MODE 1: _rasterize_triangles
-template <int MODE>
-__global__ __launch_bounds__(kRasterThreads) void raster_kernel(RasterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-    const int tid = threadIdx.x;
-    const size_t b = blockIdx.y;
-    const int tx0 = (blockIdx.x % a.tiles_x) * kTile, ty0 = (blockIdx.x / a.tiles_x) * kTile;
-    const int tw = min(kTile, a.w - tx0), th = min(kTile, a.h - ty0);
-    const float* vb = a.vertices + b * a.m.nver * 3;
-    float* depth_b = a.depth ? a.depth + b * a.h * a.w : nullptr;
+struct TriLane {  // one triangle as a lane carries it: setup, corner depths, box clipped to the item, index
+    TriSetup ts;
+    float z0, z1, z2;
+    int bx0, by0, f;
+};
 
-    for (int p = tid; p < tw * th; p += kRasterThreads) {
-        const int ly = p / tw, lx = p - ly * tw;
+// exact n / d and n % d for 0 <= n <= 512, 1 <= d <= 64: (n + 0.5) / d is at least 0.5 / d away from an integer,
+// far more than the relative 1e-7 of v_rcp_f32 on a quotient below 513
+__device__ __forceinline__ void divmod_small(int n, int d, int& q, int& r) {
+    q = (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+    r = n - q * d;
+}
+
+// MODE 0: _rasterize (strictly-interior test, colour output)   MODE 1: _rasterize_triangles
+// launch bounds: 4 waves per SIMD = two workgroups per CU (<= 128 VGPRs), so one item's latency-bound phases (sort,
+// resolve) overlap the other's ALU-bound fragment walk
+template <int MODE>
+__global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[kTile * kTile];
+    __shared__ unsigned slist[kListCap];          // triangle ids of this round, sorted by class
+    __shared__ int ccount[kClasses][kSpread];     // triangles per (class, counter copy); then write cursors
+    __shared__ int cnum[kClasses];                // triangles per class
+    __shared__ int cbase[kClasses + 1];           // first slist entry of a class
+    __shared__ int sbase[kClasses + 1];           // first lane slot of a class (multiples of 64)
+    __shared__ unsigned s_item;
+    __shared__ int step_ctr;                      // next 64-lane step of the walk to hand to a wave
+    unsigned* kw = reinterpret_cast<unsigned*>(keys);  // kw[2p] = ~triangle (low word), kw[2p+1] = depth
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ntiles = a.sc.tiles_x * a.sc.tiles_y;
+    const size_t nt = a.m.ntri;
+    const unsigned n_items = a.sc.qhdr[0];
+
+    for (;;) {
+    if (tid == 0) s_item = atomicAdd(&a.sc.qhdr[1], 1u);
+    __syncthreads();
+    const unsigned item = s_item;
+    if (item >= n_items) break;
+    const uint2 qe = a.sc.queue[item];
+    const int level = (qe.x >> 24) & 3, part = qe.x >> 26, n_total = (int)qe.y;
+    const size_t b = (qe.x & 0xFFFFFFu) / ntiles;
+    const int tile = (qe.x & 0xFFFFFFu) % ntiles;
+    // the item's pixel rectangle: the whole tile or one of its 2x2 / 4x4 parts
+    const int edge = kTile >> level;
+    const int tx0 = (tile % a.sc.tiles_x) * kTile + (part & ((1 << level) - 1)) * edge;
+    const int ty0 = (tile / a.sc.tiles_x) * kTile + (part >> level) * edge;
+    const int tw = min(edge, a.w - tx0), th = min(edge, a.h - ty0);
+    const int tx1 = tx0 + tw - 1, ty1 = ty0 + th - 1;
+    const float4* rec_b = a.sc.rec + b * nt * kRecF4;
+    const unsigned* glist = a.sc.lists + (b * ntiles + tile) * nt;
+    float* depth_b = a.depth ? a.depth + b * a.h * a.w : nullptr;
+    auto stamp = [&](int slot) {
+        if (a.trace && lane == 0) a.trace[((size_t)item * kRasterWaves + (tid >> 6)) * 16 + slot] = wall_clock64();
+    };
+    stamp(0);
+    if (tw > 0 && th > 0) {  // a part can lie beyond the image edge
+
+    for (int p = tid; p < edge * th; p += kRasterThreads) {
+        const int ly = p / edge, lx = p - ly * edge;
+        if (lx >= tw) continue;
         const float z0 = depth_b ? depth_b[(size_t)(ty0 + ly) * a.w + tx0 + lx] : -1e8f;  // Sim3DR.py:23
         keys[ly * kTile + lx] = ((unsigned long long)depth_order(z0) << 32) | kNoTri;
     }
-    __syncthreads();
 
-    // One pixel test of triangle (ts, z0..z2, lowkey) at (x, y): identical arithmetic whichever lane runs it.
-    auto fragment = [&](const TriSetup& ts, float z0, float z1, float z2, unsigned long long lowkey, int x, int y) {
+    stamp(12);
+    // (A) list entries [r * kListCap, ...) -> slist sorted by class of the box area inside the item
+    auto clipped_area = [&](float4 r3) {
+        const unsigned bx = __float_as_uint(r3.y), by = __float_as_uint(r3.z);
+        const int x0 = max((int)(bx & 0xffff), tx0), x1 = min((int)(bx >> 16), tx1);
+        const int y0 = max((int)(by & 0xffff), ty0), y1 = min((int)(by >> 16), ty1);
+        return (x1 < x0 || y1 < y0) ? 0 : (x1 - x0 + 1) * (y1 - y0 + 1);
+    };
+    auto sort_round = [&](int r) {
+        const int n = min(kListCap, n_total - r * kListCap);
+        for (int i = tid; i < kClasses * kSpread; i += kRasterThreads) (&ccount[0][0])[i] = 0;
+        __syncthreads();
+        unsigned fv[kListPerThread];
+        int cl[kListPerThread];
+        const int copy = lane & (kSpread - 1);
+#pragma unroll
+        for (int k = 0; k < kListPerThread; ++k) {
+            const int i = k * kRasterThreads + tid;
+            cl[k] = -1;
+            const unsigned e = i < n ? glist[r * kListCap + i] : ~0u;
+            if (e != ~0u) {
+                fv[k] = e & kIdMask;
+                cl[k] = (int)(e >> 28);
+                if (level > 0) {  // a part of the tile: drop the triangles that miss it, re-class the others
+                    const int area = clipped_area(rec_b[(size_t)fv[k] * kRecF4 + 3]);
+                    cl[k] = area > 0 ? area_class(area) : -1;
+                }
+                if (cl[k] >= 0) atomicAdd(&ccount[cl[k]][copy], 1);
+            }
+        }
+        __syncthreads();
+        if (r == 0) stamp(13);
+        // exclusive prefix of the (class, copy) counters = write cursors: the 16 copies of a class sit in 16
+        // consecutive lanes, scanned with shuffles; then every lane adds the totals of the classes before its own
+        int cursor = 0;
+        const int pc = tid / kSpread, pj = tid % kSpread;
+        if (tid < kClasses * kSpread) {
+            const int mine = ccount[pc][pj];
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < kSpread; o <<= 1) {
+                const int up = __shfl_up(incl, o, kSpread);
+                if (pj >= o) incl += up;
+            }
+            cursor = incl - mine;
+            if (pj == kSpread - 1) cnum[pc] = incl;
+        }
+        __syncthreads();  // also: all (class, copy) counts read before any becomes a cursor
+        if (tid < kClasses * kSpread) {
+            int before = 0, sb = 0, all = 0, sall = 0;
+#pragma unroll
+            for (int cc = 0; cc < kClasses; ++cc) {
+                const int n_cc = cnum[cc], s_cc = ((n_cc << max(cc - 2, 0)) + 63) & ~63;
+                if (cc < pc) before += n_cc, sb += s_cc;
+                all += n_cc, sall += s_cc;
+            }
+            (&ccount[0][0])[tid] = cursor + before;
+            if (pj == 0) cbase[pc] = before, sbase[pc] = sb;
+            if (tid == 0) cbase[kClasses] = all, sbase[kClasses] = sall, step_ctr = 0;
+        }
+        __syncthreads();
+        if (r == 0) stamp(14);
+#pragma unroll
+        for (int k = 0; k < kListPerThread; ++k)
+            if (cl[k] >= 0) slist[atomicAdd(&ccount[cl[k]][copy], 1)] = fv[k];
+        __syncthreads();
+    };
+
+    // Walk over the lane slots of the sorted list: pixel(t, x, y) per box pixel assigned to the lane (the lanes of a
+    // triangle stride over its row-major box).
+    // The record of the next wave step is requested before the pixels of the current one are worked on.
+    struct Slot {
+        float4 r0, r1, r2, r3;
+        int f, sub, lg;
+        bool valid;
+    };
+    auto walk = [&](int trace_base, auto&& pixel) {
+        int sb[kClasses + 1];
+#pragma unroll
+        for (int c = 0; c <= kClasses; ++c) sb[c] = __builtin_amdgcn_readfirstlane(sbase[c]);
+        auto fetch = [&](int s0, Slot& sl) {  // s0 is wave-uniform
+            sl.valid = false;
+            if (s0 >= sb[kClasses]) return;
+            int c = 0;
+#pragma unroll
+            for (int k = 1; k < kClasses; ++k) c += (s0 >= sb[k]) ? 1 : 0;
+            sl.lg = max(c - 2, 0);
+            const int local = s0 + lane - sbase[c];
+            const int ti = local >> sl.lg;
+            sl.sub = local & ((1 << sl.lg) - 1);
+            if (ti >= cnum[c]) return;
+            sl.f = (int)slist[cbase[c] + ti];
+            const float4* rp = rec_b + (size_t)sl.f * kRecF4;
+            sl.r0 = rp[0], sl.r1 = rp[1], sl.r2 = rp[2], sl.r3 = rp[3];
+            sl.valid = true;
+        };
+        // waves take steps from an LDS counter: a step costs 1 to 8 pixel tests per lane, mostly outside or mostly
+        // inside its triangle, so a fixed assignment left some waves with twice the work of others
+        auto next_step = [&]() {
+            int st = 0;
+            if (lane == 0) st = atomicAdd(&step_ctr, 1);
+            return __builtin_amdgcn_readfirstlane(st) * 64;
+        };
+        Slot cur, nxt;
+        int s0 = next_step();
+        fetch(s0, cur);
+        unsigned long long d_steps = 0, d_wait = 0, d_work = 0, d_trips = 0;  // diagnostics (a.trace only)
+        while (s0 < sb[kClasses]) {
+            s0 = next_step();
+            fetch(s0, nxt);
+            unsigned long long c0 = 0, c1 = 0;
+            if (a.trace) {
+                c0 = wall_clock64();
+                __builtin_amdgcn_s_waitcnt(0);
+                c1 = wall_clock64();
+                d_wait += c1 - c0, ++d_steps;
+            }
+            if (cur.valid) {
+                TriLane t;
+                t.f = cur.f;
+                t.ts.x0 = cur.r0.x, t.ts.y0 = cur.r0.y, t.ts.ax = cur.r0.z, t.ts.ay = cur.r0.w;
+                t.ts.bx = cur.r1.x, t.ts.by = cur.r1.y, t.ts.d00 = cur.r1.z, t.ts.d01 = cur.r1.w;
+                t.ts.d11 = cur.r2.x, t.ts.inv = cur.r2.y, t.z0 = cur.r2.z, t.z1 = cur.r2.w, t.z2 = cur.r3.x;
+                const unsigned bbx = __float_as_uint(cur.r3.y), bby = __float_as_uint(cur.r3.z);
+                t.bx0 = max((int)(bbx & 0xffff), tx0);
+                t.by0 = max((int)(bby & 0xffff), ty0);
+                const int bw = min((int)(bbx >> 16), tx1) - t.bx0 + 1, bh = min((int)(bby >> 16), ty1) - t.by0 + 1;
+                const int area = bw * bh, g = 1 << cur.lg;
+                int x, y, gq, gr;
+                divmod_small(cur.sub, bw, y, x);
+                divmod_small(g, bw, gq, gr);
+                for (int j = cur.sub; j < area; j += g) {
+                    pixel(t, t.bx0 + x, t.by0 + y);
+                    y += gq, x += gr;
+                    if (x >= bw) x -= bw, ++y;
+                    if (a.trace) ++d_trips;
+                }
+            }
+            if (a.trace) d_work += wall_clock64() - c1;
+            cur = nxt;
+        }
+        if (a.trace) {
+            unsigned long long mx = d_trips;
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned long long)__shfl_xor((long long)mx, o));
+            if (lane == 0) {
+                unsigned long long* tr = a.trace + ((size_t)item * kRasterWaves + (tid >> 6)) * 16 + trace_base;
+                tr[0] = d_steps, tr[1] = d_wait, tr[2] = d_work, tr[3] = mx;
+            }
+        }
+    };
+
+    // (B) one pixel test: identical arithmetic whichever lane runs it (get_point_weight / is_point_in_tri)
+    auto fragment = [&](const TriLane& t, int x, int y) {
         float u, v;
-        tri_uv(ts, (float)x, (float)y, u, v);
+        tri_uv(t.ts, (float)x, (float)y, u, v);
         const float w0 = 1.0f - u - v;
         const bool inside = (MODE == 0) ? (u > 0.0f && v > 0.0f && w0 > 0.0f) : (u >= 0.0f && v >= 0.0f && (u + v < 1.0f));
         if (!inside) return;
-        const float z = w0 * z0 + v * z1 + u * z2;
+        const float z = w0 * t.z0 + v * t.z1 + u * t.z2;
         if (z != z) return;  // NaN never passes `>`
-        const unsigned long long key = ((unsigned long long)depth_order(z) << 32) | lowkey;
+        const unsigned long long key = ((unsigned long long)depth_order(z) << 32) | (0xFFFFFFFEu - (unsigned)t.f);
         // fire-and-forget ds_max_u64: no returned value, so the wave never waits on the LDS round trip
         (void)__hip_atomic_fetch_max(&keys[(y - ty0) * kTile + (x - tx0)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    // Lanes stride over the triangle list. Small boxes are scanned by the owning lane; a box of more than
-    // kBigBox pixels (a few percent of the triangles, about half of all pixel tests on a head mesh) is handed to
-    // the whole wave -- its setup is broadcast with v_readlane and the 64 lanes share the box -- otherwise one
-    // lane with an 800-pixel box would hold 63 idle lanes for thousands of cycles.
-    constexpr int kBigBox = 32;
-    const int lane = tid & 63;
-    for (int f0 = tid - lane; f0 < a.m.ntri; f0 += kRasterThreads) {  // f0 is wave-uniform: no lane leaves early
-        const int f = f0 + lane;
-        bool valid = f < a.m.ntri;
-        int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
-        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        TriSetup ts{};
-        if (valid) {
-            const int i0 = a.m.tri[3 * f], i1 = a.m.tri[3 * f + 1], i2 = a.m.tri[3 * f + 2];
-            const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1];
-            const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1];
-            const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1];
-            z0 = vb[3 * i0 + 2], z1 = vb[3 * i1 + 2], z2 = vb[3 * i2 + 2];
-            // bounding box exactly as rasterize_kernel.cpp:246-254, then clipped to this tile
-            bx0 = max(f2i_x86(ceilf(std_min(x0, std_min(x1, x2)))), 0);
-            bx1 = min(f2i_x86(floorf(std_max(x0, std_max(x1, x2)))), a.w - 1);
-            by0 = max(f2i_x86(ceilf(std_min(y0, std_min(y1, y2)))), 0);
-            by1 = min(f2i_x86(floorf(std_max(y0, std_max(y1, y2)))), a.h - 1);
-            valid = !(bx1 < bx0 || by1 < by0);
-            bx0 = max(bx0, tx0);
-            bx1 = min(bx1, tx0 + tw - 1);
-            by0 = max(by0, ty0);
-            by1 = min(by1, ty0 + th - 1);
-            valid = valid && !(bx1 < bx0 || by1 < by0);
-            if (valid) ts = tri_setup(x0, y0, x1, y1, x2, y2);
-        }
-        const unsigned long long lowkey = 0xFFFFFFFEu - (unsigned)f;
-        const bool big = valid && (bx1 - bx0 + 1) * (by1 - by0 + 1) > kBigBox;
-        if (valid && !big)
-            for (int y = by0; y <= by1; ++y)
-                for (int x = bx0; x <= bx1; ++x) fragment(ts, z0, z1, z2, lowkey, x, y);
-        unsigned long long pending = __ballot(big);
-        while (pending) {
-            const int src = __builtin_ctzll(pending);
-            pending &= pending - 1;
-            auto bi = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
-            auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-            TriSetup t2;
-            t2.x0 = bf(ts.x0), t2.y0 = bf(ts.y0), t2.ax = bf(ts.ax), t2.ay = bf(ts.ay), t2.bx = bf(ts.bx), t2.by = bf(ts.by);
-            t2.d00 = bf(ts.d00), t2.d01 = bf(ts.d01), t2.d11 = bf(ts.d11), t2.inv = bf(ts.inv);
-            const float s0 = bf(z0), s1 = bf(z1), s2 = bf(z2);
-            const int cx0 = bi(bx0), cx1 = bi(bx1), cy0 = bi(by0), cy1 = bi(by1);
-            const unsigned long long lk = 0xFFFFFFFEu - (unsigned)(f0 + src);
-            // lanes tile the box as lw x (64/lw), lw = the power of two covering min(width, 64)
-            const int bw = cx1 - cx0 + 1;
-            const int sh = bw > 32 ? 6 : bw > 16 ? 5 : bw > 8 ? 4 : 3;
-            const int lx = lane & ((1 << sh) - 1), ly = lane >> sh;
-            for (int y = cy0 + ly; y <= cy1; y += 64 >> sh)
-                for (int x = cx0 + lx; x <= cx1; x += 1 << sh) fragment(t2, s0, s1, s2, lk, x, y);
-        }
-    }
-    __syncthreads();
 
-    // Resolve: every pixel is shaded once from its winning triangle. A thread owns four horizontally adjacent
-    // pixels: their dependent gathers (triangle -> vertices -> colours) overlap, and when the row pitch allows it
-    // the 4*c colour bytes are merged into the background as whole dwords (byte stores are read-modify-writes in
-    // L2: 3 loads + 3 stores per pixel made this pass the longest of the kernel).
-    constexpr int NB = 4;
-    const float* cb = (MODE == 0) ? a.colors + b * a.m.nver * a.c : nullptr;
-    const int qw = (tw + NB - 1) / NB;  // pixel quads per tile row
-    // C = compile-time channel count of the packed path (3: RGB, 4: RGBA), 0 = any count, bytewise
+    const int nrounds = (n_total + kListCap - 1) / kListCap;  // 1 for a head mesh: the list is sorted once
+    for (int r = 0; r < nrounds; ++r) {
+        sort_round(r);  // its first barrier also orders the key initialisation before the atomics
+        if (r == 0) stamp(1);
+        walk(8, fragment);
+        if (nrounds > 1) __syncthreads();
+    }
+    stamp(2);
+    __syncthreads();
+    stamp(3);
+
+    // (C) resolve: every pixel is shaded once from its winning triangle. A thread owns four horizontally adjacent
+    // pixels; their records (one 64-byte line each), vertex indices and colours are requested together so the two
+    // dependent memory round trips are paid once per quad, and when the row pitch allows it the 4*c colour bytes are
+    // merged into the background as whole dwords (byte stores are read-modify-writes in L2). The cost is the same
+    // for an item with 100 triangles and one with 4000.
+    // C = compile-time channel count of the packed path (3: RGB, 4: RGBA), 0 = any count, bytewise.
+    const float* cb_ = (MODE == 0) ? a.colors + b * a.m.nver * a.c : nullptr;
     auto resolve = [&](auto cc) {
-    constexpr int C = decltype(cc)::value;
-    const int nc = C ? C : a.c;
-    const bool packed = MODE == 0 && C != 0;
-    for (int q = tid; q < qw * th; q += kRasterThreads) {
-        const int ly = q / qw, lx0 = (q - ly * qw) * NB;
-        const int gy = ty0 + ly;
-        int f[NB], i0[NB], i1[NB], i2[NB];
-        bool hit[NB];
+        constexpr int C = decltype(cc)::value;
+        constexpr bool packed = MODE == 0 && C != 0;
+        constexpr int CC = C ? C : 1;
+        constexpr int NB = 4;
+        const int nc = C ? C : a.c;
+        const int qrow = edge / NB;  // quads per row of the item
+        for (int q = tid; q < qrow * th; q += kRasterThreads) {
+            const int ly = q / qrow, lx0 = (q - ly * qrow) * NB;
+            if (lx0 >= tw) continue;
+            const uint4 k01 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0)]);
+            const uint4 k23 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0) + 4]);
+            const unsigned lo[NB] = {k01.x, k01.z, k23.x, k23.z};
+            bool hit[NB];
+            unsigned f[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const unsigned low = (lx0 + k < tw) ? (unsigned)keys[ly * kTile + lx0 + k] : kNoTri;
-            hit[k] = low != kNoTri;  // kNoTri: nothing beat the incoming depth, the pixel stays untouched
-            f[k] = hit[k] ? (int)(0xFFFFFFFEu - low) : 0;
-        }
-        if (!(hit[0] || hit[1] || hit[2] || hit[3])) continue;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
-        float vx[NB][9];
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vx[k][c] = vb[3 * i0[k] + c], vx[k][3 + c] = vb[3 * i1[k] + c], vx[k][6 + c] = vb[3 * i2[k] + c];
-        const int row = (MODE == 0 && a.reverse) ? (a.h - 1 - gy) : gy;
-        unsigned char bytes[C ? 4 * C : 4];
-        unsigned* quad = nullptr;
-        if (packed) {
-            quad = reinterpret_cast<unsigned*>(a.image + ((b * a.h + row) * a.w + tx0 + lx0) * nc);
-#pragma unroll
-            for (int d = 0; d < C; ++d) {
-                const unsigned wv = quad[d];
-                bytes[4 * d] = wv & 0xff, bytes[4 * d + 1] = (wv >> 8) & 0xff, bytes[4 * d + 2] = (wv >> 16) & 0xff, bytes[4 * d + 3] = wv >> 24;
+            for (int k = 0; k < NB; ++k) {
+                hit[k] = lx0 + k < tw && lo[k] != kNoTri;  // kNoTri: nothing beat the incoming depth
+                f[k] = hit[k] ? 0xFFFFFFFEu - lo[k] : 0u;
             }
-        }
+            if (!(hit[0] || hit[1] || hit[2] || hit[3])) continue;
+            float4 r0[NB], r1[NB], r2[NB];
+            float z2[NB];
+            int i0[NB], i1[NB], i2[NB];
+            // a pixel with the same triangle as its left neighbour copies instead of loading (large triangles: most)
+            bool same[NB];
+            same[0] = false;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            if (!hit[k]) continue;
-            const int gx = tx0 + lx0 + k;
-            const TriSetup ts = tri_setup(vx[k][0], vx[k][1], vx[k][3], vx[k][4], vx[k][6], vx[k][7]);
-            float u, v;
-            tri_uv(ts, (float)gx, (float)gy, u, v);
-            const float w0 = 1.0f - u - v;
-            const float z = w0 * vx[k][2] + v * vx[k][5] + u * vx[k][8];
-            const size_t pix = (size_t)gy * a.w + gx;
-            if (depth_b) depth_b[pix] = z;
-            if (MODE == 0) {
-                uint8_t* px = a.image + ((b * a.h + row) * a.w + gx) * nc;
-                // (unsigned char)((1 - alpha) * old + alpha * 255 * col) with alpha == 1
-                if (packed) {
+            for (int k = 1; k < NB; ++k) same[k] = f[k] == f[k - 1];
 #pragma unroll
-                    for (int ch = 0; ch < C; ++ch) {
-                        const float col = w0 * cb[C * i0[k] + ch] + v * cb[C * i1[k] + ch] + u * cb[C * i2[k] + ch];
-                        unsigned char& o = bytes[k * C + ch];
-                        o = (unsigned char)(f2i_x86(0.0f * (float)o + 255.0f * col) & 0xff);
-                    }
-                } else {
-                    for (int ch = 0; ch < nc; ++ch) {
-                        const float col = w0 * cb[nc * i0[k] + ch] + v * cb[nc * i1[k] + ch] + u * cb[nc * i2[k] + ch];
-                        px[ch] = (uint8_t)(f2i_x86(0.0f * (float)px[ch] + 255.0f * col) & 0xff);
+            for (int k = 0; k < NB; ++k) {
+                if (!same[k]) {
+                    const float4* rp = rec_b + (size_t)f[k] * kRecF4;
+                    r0[k] = rp[0], r1[k] = rp[1], r2[k] = rp[2], z2[k] = rp[3].x;
+                    if (MODE == 0) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < NB; ++k) {
+                if (same[k]) {
+                    r0[k] = r0[k - 1], r1[k] = r1[k - 1], r2[k] = r2[k - 1], z2[k] = z2[k - 1];
+                    if (MODE == 0) i0[k] = i0[k - 1], i1[k] = i1[k - 1], i2[k] = i2[k - 1];
+                }
+            }
+            const int gy = ty0 + ly;
+            const int row = (MODE == 0 && a.reverse) ? (a.h - 1 - gy) : gy;
+            float u[NB], v[NB], w0[NB], z[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                TriSetup ts;
+                ts.x0 = r0[k].x, ts.y0 = r0[k].y, ts.ax = r0[k].z, ts.ay = r0[k].w, ts.bx = r1[k].x, ts.by = r1[k].y;
+                ts.d00 = r1[k].z, ts.d01 = r1[k].w, ts.d11 = r2[k].x, ts.inv = r2[k].y;
+                tri_uv(ts, (float)(tx0 + lx0 + k), (float)gy, u[k], v[k]);
+                w0[k] = 1.0f - u[k] - v[k];
+                z[k] = w0[k] * r2[k].z + v[k] * r2[k].w + u[k] * z2[k];
+            }
+            // the records are dead from here on: only now ask for the colours, or 4 x (13 + 3 + 9) registers are live
+            __builtin_amdgcn_sched_barrier(0);
+            float col[NB][3 * CC];
+            if (packed) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (same[k]) continue;
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch)
+                        col[k][ch] = cb_[C * i0[k] + ch], col[k][C + ch] = cb_[C * i1[k] + ch], col[k][2 * C + ch] = cb_[C * i2[k] + ch];
+                }
+#pragma unroll
+                for (int k = 1; k < NB; ++k) {
+                    if (!same[k]) continue;
+#pragma unroll
+                    for (int ch = 0; ch < 3 * C; ++ch) col[k][ch] = col[k - 1][ch];
+                }
+            }
+            const size_t pix0 = (size_t)gy * a.w + tx0 + lx0;
+            if (depth_b) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (hit[k]) depth_b[pix0 + k] = z[k];
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (!hit[k]) continue;
+                    a.tri_buf[b * a.h * a.w + pix0 + k] = (int)f[k];
+                    float* bw = a.bary + (b * a.h * a.w + pix0 + k) * 3;
+                    bw[0] = w0[k];
+                    bw[1] = v[k];
+                    bw[2] = u[k];
+                }
+            } else if (packed) {
+                // (unsigned char)((1 - alpha) * old + alpha * 255 * col) with alpha == 1: the old value only
+                // contributes +0.0f, so the background is read only where the quad is partly covered
+                unsigned* quad = reinterpret_cast<unsigned*>(a.image + ((b * a.h + row) * a.w + tx0 + lx0) * CC);
+                unsigned char bytes[4 * CC];
+                if (!(hit[0] && hit[1] && hit[2] && hit[3])) {
+#pragma unroll
+                    for (int d = 0; d < CC; ++d) {
+                        const unsigned wv = quad[d];
+                        bytes[4 * d] = wv & 0xff, bytes[4 * d + 1] = (wv >> 8) & 0xff, bytes[4 * d + 2] = (wv >> 16) & 0xff, bytes[4 * d + 3] = wv >> 24;
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (!hit[k]) continue;
+#pragma unroll
+                    for (int ch = 0; ch < CC; ++ch) {
+                        const float cv = w0[k] * col[k][ch] + v[k] * col[k][CC + ch] + u[k] * col[k][2 * CC + ch];
+                        bytes[k * CC + ch] = (unsigned char)(f2i_x86(0.0f + 255.0f * cv) & 0xff);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < CC; ++d)
+                    quad[d] = (unsigned)bytes[4 * d] | ((unsigned)bytes[4 * d + 1] << 8) | ((unsigned)bytes[4 * d + 2] << 16) | ((unsigned)bytes[4 * d + 3] << 24);
             } else {
-                a.tri_buf[b * a.h * a.w + pix] = f[k];
-                float* bw = a.bary + (b * a.h * a.w + pix) * 3;
-                bw[0] = w0;
-                bw[1] = v;
-                bw[2] = u;
+                for (int k = 0; k < NB; ++k) {
+                    if (!hit[k]) continue;
+                    uint8_t* px = a.image + ((b * a.h + row) * a.w + tx0 + lx0 + k) * nc;
+                    for (int ch = 0; ch < nc; ++ch) {
+                        const float cv = w0[k] * cb_[nc * i0[k] + ch] + v[k] * cb_[nc * i1[k] + ch] + u[k] * cb_[nc * i2[k] + ch];
+                        px[ch] = (uint8_t)(f2i_x86(0.0f + 255.0f * cv) & 0xff);
+                    }
+                }
             }
         }
-        if (packed) {
-#pragma unroll
-            for (int d = 0; d < C; ++d)
-                quad[d] = (unsigned)bytes[4 * d] | ((unsigned)bytes[4 * d + 1] << 8) | ((unsigned)bytes[4 * d + 2] << 16) | ((unsigned)bytes[4 * d + 3] << 24);
-        }
-    }
     };
-    const bool can_pack = MODE == 0 && (a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.image) & 3) == 0;
-    if (can_pack && a.c == 3) resolve(std::integral_constant<int, 3>{});
-    else if (can_pack && a.c == 4) resolve(std::integral_constant<int, 4>{});
-    else resolve(std::integral_constant<int, 0>{});
+    {
+        const bool can_pack = MODE == 0 && (a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.image) & 3) == 0;
+        if (can_pack && a.c == 3) resolve(std::integral_constant<int, 3>{});
+        else if (can_pack && a.c == 4) resolve(std::integral_constant<int, 4>{});
+        else resolve(std::integral_constant<int, 0>{});
+    }
+    }  // part inside the image
+    stamp(4);
+    if (a.trace && tid == 0) {
+        unsigned long long* tr = a.trace + (size_t)item * kRasterWaves * 16;
+        tr[5] = qe.x, tr[6] = n_items, tr[7] = n_total;
+    }
+    __syncthreads();  // keys, slist and s_item are reused by the next item
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,25 +833,80 @@ dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float*
     return DAD3D_OK;
 }
 
-dad3d_status launch_rasterize(const MeshDev& m, uint8_t* image, const float* vertices, const float* colors,
-                              float* depth, int32_t* tri_buf, float* bary, int batch, int h, int w, int c,
-                              int reverse, int mode, hipStream_t s) {
-    if (batch == 0 || h == 0 || w == 0) return DAD3D_OK;
-    static bool attr_done = false;
-    const size_t lds = (size_t)kTile * kTile * sizeof(unsigned long long);
-    if (!attr_done) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&raster_kernel<0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&raster_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+namespace {
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int tiles_of(int extent) { return (extent + kTile - 1) / kTile; }
+struct ScratchLayout {
+    size_t rec, counts, qhdr, queue, lists, total;
+    ScratchLayout(const MeshDev& m, int batch, int h, int w) {
+        const size_t nt = m.ntri, nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
+        rec = 0;
+        counts = align256(rec + batch * nt * kRecF4 * sizeof(float4));
+        qhdr = align256(counts + 2 * nlists * sizeof(unsigned));
+        queue = align256(qhdr + 2 * sizeof(unsigned));
+        lists = align256(queue + nlists * kMaxSubs * sizeof(uint2));
+        total = align256(lists + nlists * nt * sizeof(unsigned));
     }
-    RasterArgs a{m, image, vertices, colors, depth, tri_buf, bary, h, w, c, reverse, (w + kTile - 1) / kTile};
-    const dim3 grid(a.tiles_x * ((h + kTile - 1) / kTile), batch);
+};
+}  // namespace
+
+size_t raster_scratch_bytes(const MeshDev& m, int batch, int h, int w) { return ScratchLayout(m, batch, h, w).total; }
+
+// the tile counters must be zero before the first launch with a new (batch, h, w); afterwards the queue kernel
+// leaves them zero
+dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int h, int w, hipStream_t s) {
+    const ScratchLayout lay(m, batch, h, w);
+    DAD3D_HIP_TRY(hipMemsetAsync(static_cast<char*>(scratch) + lay.counts, 0, lay.queue - lay.counts, s));
+    return DAD3D_OK;
+}
+
+dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image,
+                              const float* vertices, const float* colors, float* depth, int32_t* tri_buf, float* bary,
+                              int batch, int h, int w, int c, int reverse, int mode, hipStream_t s) {
+    if (batch == 0 || h == 0 || w == 0 || m.ntri == 0) return DAD3D_OK;  // nothing to draw: buffers stay as they are
+    const size_t nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
+    DAD3D_REQUIRE(h <= 65535 && w <= 65535 && tiles_of(h) * tiles_of(w) <= kMaxTiles && nlists < (1u << 24),
+                  "rasterize: %d images of %dx%d exceed %d tiles of %dx%d pixels per image or 2^24 in total", batch, h,
+                  w, kMaxTiles, kTile, kTile);
+    DAD3D_REQUIRE((unsigned)m.ntri <= kIdMask, "rasterize: more than 2^28 triangles");
+    DAD3D_REQUIRE(scratch, "rasterize: no scratch buffer");
+    static int persistent_blocks[2] = {0, 0};
+    constexpr int kMaxLds = 160 * 1024;
+    if (!persistent_blocks[0]) {
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        int dev = 0, cus = 0, per_cu[2] = {0, 0};
+        DAD3D_HIP_TRY(hipGetDevice(&dev));
+        DAD3D_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        DAD3D_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], raster_kernel<0>, kRasterThreads, 0));
+        DAD3D_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], raster_kernel<1>, kRasterThreads, 0));
+        persistent_blocks[1] = std::max(1, cus * per_cu[1]);
+        persistent_blocks[0] = std::max(1, cus * per_cu[0]);
+    }
+    const ScratchLayout lay(m, batch, h, w);
+    char* base = static_cast<char*>(scratch);
+    RasterScratch sc{reinterpret_cast<float4*>(base + lay.rec),    reinterpret_cast<unsigned*>(base + lay.counts),
+                     reinterpret_cast<unsigned*>(base + lay.lists), reinterpret_cast<unsigned*>(base + lay.qhdr),
+                     reinterpret_cast<uint2*>(base + lay.queue),    tiles_of(w), tiles_of(h)};
+    const int ntiles = sc.tiles_x * sc.tiles_y;
+    {
+        const dim3 ggrid((m.ntri + kGeoTrisPerBlock - 1) / kGeoTrisPerBlock, batch);
+        const size_t cnt_bytes = 2 * (size_t)ntiles * sizeof(unsigned);
+        const size_t vlds = ((size_t)m.nver * 3 + 8) * sizeof(float) + cnt_bytes;
+        if (vlds <= (size_t)kMaxLds)
+            hipLaunchKernelGGL(tri_geometry_kernel<true>, ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w);
+        else
+            hipLaunchKernelGGL(tri_geometry_kernel<false>, ggrid, dim3(kGeoThreads), 32 + cnt_bytes, s, m, vertices, sc, h, w);
+        DAD3D_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(raster_queue_kernel, dim3(1), dim3(1024), 0, s, sc, (int)nlists);
+    DAD3D_HIP_TRY(hipGetLastError());
+    RasterArgs a{m, sc, image, colors, depth, tri_buf, bary, trace, h, w, c, reverse};
+    const int blocks = (int)std::min<size_t>(persistent_blocks[mode ? 1 : 0], nlists * kMaxSubs);
     if (mode == 0)
-        hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(kRasterThreads), lds, s, a);
+        hipLaunchKernelGGL(raster_kernel<0>, dim3(blocks), dim3(kRasterThreads), 0, s, a);
     else
-        hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(kRasterThreads), lds, s, a);
+        hipLaunchKernelGGL(raster_kernel<1>, dim3(blocks), dim3(kRasterThreads), 0, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

@@ -169,6 +169,12 @@ typedef struct dad3d_light {
 } dad3d_light;
 dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,
                                     int batch, const dad3d_light* cfg, void* stream);
+/* Diagnostics: DEVICE buffer of [B * tiles][8 waves][16] uint64 that every wave of the raster kernel fills with
+ * 100 MHz wall-clock stamps at its phase boundaries (slots 0-6: start, list sorted, fragments done, after barrier,
+ * shaded, after barrier, end; 7: triangles in the tile list; 8-11 / 12-15: wave steps, ticks waiting for records,
+ * ticks working, pixel tests of the busiest lane, for the fragment / shading walk); NULL switches it off.
+ * tiles = ceil(w/64) * ceil(h/64). */
+dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer);
 
 /* Single-image HOST entry points with the argument lists of Sim3DR/lib/rasterize.h:84-100 (`bool` spelled
  * `int` for C). libdad3d_hip.so additionally exports the C++-linkage symbols `_get_tri_normal`,
