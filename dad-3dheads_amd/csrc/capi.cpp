@@ -390,8 +390,7 @@ struct dad3d_mesh {
     int device = 0;
     int ntri = 0, nver = 0;
     int *d_tri = nullptr, *d_adj_ptr = nullptr, *d_adj_face = nullptr;
-    float* d_scratch = nullptr;
-    int scratch_batch = 0;
+    int4* d_adj_tri = nullptr;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_mesh_debug_trace)
     void* d_raster = nullptr;  // per-image triangle boxes + corner planes, grown on demand (one stream at a time)
     size_t raster_bytes = 0;
@@ -413,7 +412,7 @@ struct dad3d_mesh {
         raster_batch = batch, raster_h = h, raster_w = w;
         return DAD3D_OK;
     }
-    MeshDev dev() const { return MeshDev{d_tri, d_adj_ptr, d_adj_face, ntri, nver}; }
+    MeshDev dev() const { return MeshDev{d_tri, d_adj_ptr, d_adj_face, d_adj_tri, ntri, nver}; }
 };
 
 extern "C" {
@@ -438,8 +437,14 @@ dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int devic
     m->ntri = ntri;
     m->nver = nver;
     std::vector<int> tri_v(tri, tri + 3 * (size_t)ntri);
+    std::vector<int4> adj_tri(face.size());
+    for (size_t e = 0; e < face.size(); ++e) {
+        const int f = face[e];
+        adj_tri[e] = make_int4(tri[3 * f], tri[3 * f + 1], tri[3 * f + 2], f);
+    }
     dad3d_status st;
-    if ((st = upload(&m->d_tri, tri_v)) || (st = upload(&m->d_adj_ptr, ptr)) || (st = upload(&m->d_adj_face, face))) {
+    if ((st = upload(&m->d_tri, tri_v)) || (st = upload(&m->d_adj_ptr, ptr)) || (st = upload(&m->d_adj_face, face)) ||
+        (st = upload(&m->d_adj_tri, adj_tri))) {
         dad3d_mesh_destroy(m.release());
         return st;
     }
@@ -450,7 +455,7 @@ dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int devic
 void dad3d_mesh_destroy(dad3d_mesh* m) {
     if (!m) return;
     DeviceGuard guard(m->device);
-    for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_scratch, m->d_raster})
+    for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_adj_tri, m->d_raster})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -523,15 +528,7 @@ dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* ve
     if (batch == 0 || m->nver == 0) return DAD3D_OK;
     DAD3D_REQUIRE(light && vertices && normals, "dad3d_mesh_phong_light: null buffer");
     DeviceGuard guard(m->device);
-    if (batch > m->scratch_batch) {
-        DAD3D_HIP_TRY(hipDeviceSynchronize());
-        if (m->d_scratch) (void)hipFree(m->d_scratch);
-        m->d_scratch = nullptr;
-        m->scratch_batch = 0;
-        DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_scratch), (size_t)batch * 6 * sizeof(float)));
-        m->scratch_batch = batch;
-    }
-    return launch_phong(m->dev(), light, vertices, normals, batch, *cfg, m->d_scratch, static_cast<hipStream_t>(stream));
+    return launch_phong(m->dev(), light, vertices, normals, batch, *cfg, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

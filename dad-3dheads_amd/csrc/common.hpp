@@ -109,6 +109,7 @@ struct MeshDev {
     const int* tri;       // [ntri,3]
     const int* adj_ptr;   // [nver+1]   CSR rows: (face, corner) incidences of a vertex, ascending face order
     const int* adj_face;  // [3*ntri]
+    const int4* adj_tri;  // [3*ntri]   the three corner indices of adj_face[e] (and the face index)
     int ntri, nver;
 };
 
@@ -126,6 +127,6 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
                               const float* colors, float* depth, int32_t* tri_buf, float* bary, int batch, int h,
                               int w, int c, int reverse, int mode, hipStream_t s);
 dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals, int batch,
-                          const dad3d_light& cfg, float* scratch, hipStream_t s);
+                          const dad3d_light& cfg, hipStream_t s);
 
 }  // namespace dad3d

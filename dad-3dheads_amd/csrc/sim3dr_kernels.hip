@@ -84,6 +84,26 @@ __device__ __forceinline__ void unit3(float n[3]) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS staging of one image's vertex array
+// ------------------------------------------------------------------------------------------------
+// Copies src[0, n) (4-byte aligned) into LDS so that the result pointer lv satisfies lv[e] == src[e]. The LDS image is
+// shifted by up to 3 floats so that the 16-byte aligned part of src moves as float4 on both sides. `lds` needs n + 8
+// floats. Every gather kernel below does this first: a scattered 4-byte global load costs a 64-byte request per lane.
+constexpr int kStageThreads = 1024;
+__device__ __forceinline__ float* stage_floats(float* lds, const float* src, int n, int tid) {
+    const int head = min(n, (int)(((16 - (reinterpret_cast<uintptr_t>(src) & 15)) & 15) >> 2));
+    float* lv = lds + ((4 - head) & 3);
+    const int n4 = (n - head) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(src + head);
+    float4* l4 = reinterpret_cast<float4*>(lv + head);
+    for (int i = tid; i < n4; i += kStageThreads) l4[i] = g4[i];
+    if (tid < head) lv[tid] = src[tid];
+    const int tail0 = head + 4 * n4;
+    if (tid < n - tail0) lv[tail0 + tid] = src[tail0 + tid];
+    return lv;
+}
+
+// ------------------------------------------------------------------------------------------------
 // normals
 // ------------------------------------------------------------------------------------------------
 __global__ void tri_normal_kernel(MeshDev m, float* tri_normal, const float* vertices, int norm_flg) {
@@ -127,6 +147,44 @@ __global__ void ver_normal_kernel(MeshDev m, float* ver_normal, const float* src
     d[2] = acc[2];
 }
 
+// _get_normal with the image's vertices staged in LDS: block = (vertex chunk, image). The incidence list carries
+// the three corner indices of every incident face (adj_tri), so a vertex costs one 16-byte load per incident face and
+// nine LDS reads instead of thirteen scattered global loads. Same arithmetic and summation order as above.
+constexpr int kAdjAhead = 8;  // incident faces requested together (FLAME: valence <= 8 for 99 % of the vertices)
+__global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m, float* ver_normal, const float* vertices,
+                                                                       unsigned flags, int verts_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_n[];
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const float* lv = stage_floats(lds_n, vertices + b * m.nver * 3, m.nver * 3, tid);
+    __syncthreads();
+    const int v_end = min(m.nver, ((int)blockIdx.x + 1) * verts_per_block);
+    for (int v = blockIdx.x * verts_per_block + tid; v < v_end; v += kStageThreads) {
+        const int e0 = m.adj_ptr[v], e1 = m.adj_ptr[v + 1];
+        int4 t[kAdjAhead];  // one round trip for the whole row instead of one per incident face
+#pragma unroll
+        for (int j = 0; j < kAdjAhead; ++j) t[j] = (e0 + j < e1) ? m.adj_tri[e0 + j] : make_int4(0, 0, 0, 0);
+        float* d = ver_normal + (b * m.nver + v) * 3;
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+        if (flags & DAD3D_NORMAL_ACCUMULATE) acc[0] = d[0], acc[1] = d[1], acc[2] = d[2];
+        auto add_face = [&](const int4& f) {
+            float n[3];
+            face_cross(lv, f.x, f.y, f.z, n);
+            acc[0] += n[0];
+            acc[1] += n[1];
+            acc[2] += n[2];
+        };
+#pragma unroll
+        for (int j = 0; j < kAdjAhead; ++j)
+            if (e0 + j < e1) add_face(t[j]);
+        for (int e = e0 + kAdjAhead; e < e1; ++e) add_face(m.adj_tri[e]);
+        unit3(acc);
+        d[0] = acc[0];
+        d[1] = acc[1];
+        d[2] = acc[2];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rasterisation
 // ------------------------------------------------------------------------------------------------
@@ -158,7 +216,7 @@ constexpr int kClasses = 12;         // box area <=2, <=4, <=8, <=16, ... <=4096
 constexpr int kSpread = 16;          // copies of every class counter: 64 lanes hit 16 addresses instead of one
 constexpr int kRecF4 = 4;            // one 64-byte record per (image, triangle): x0 y0 ax ay | bx by d00 d01 |
                                      // d11 inv z0 z1 | z2 box.x box.y 0  -- exactly one cache line, read as 4 x b128
-constexpr int kGeoThreads = 1024;
+constexpr int kGeoThreads = kStageThreads;
 constexpr int kGeoPerThread = 3;
 constexpr int kGeoTrisPerBlock = kGeoThreads * kGeoPerThread;
 constexpr int kMaxTiles = 4096;      // LDS counters of the geometry kernel
@@ -200,22 +258,11 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     const size_t b = blockIdx.y;
     const int ntiles = sc.tiles_x * sc.tiles_y;
     const float* vb = vertices + b * m.nver * 3;
-    // lv[e] == vb[e]; the LDS image is shifted so that the 16-byte aligned part of vb moves as float4
     const int n = LDS_VERTS ? m.nver * 3 : 0;
-    const int head = LDS_VERTS ? min(n, (int)(((16 - (reinterpret_cast<uintptr_t>(vb) & 15)) & 15) >> 2)) : 0;
-    float* lv = lds_v + ((4 - head) & 3);
-    unsigned* cnt = reinterpret_cast<unsigned*>(lds_v + ((n + 7) & ~3));  // [ntiles] block-local counts, then cursors
-    unsigned* asum = cnt + ntiles;                                        // [ntiles] block-local box area sums
+    unsigned* cnt = reinterpret_cast<unsigned*>(lds_v + ((n + 11) & ~3));  // [ntiles] block-local counts, then cursors
+    unsigned* asum = cnt + ntiles;                                         // [ntiles] block-local box area sums
     for (int t = tid; t < 2 * ntiles; t += kGeoThreads) cnt[t] = 0;
-    if (LDS_VERTS) {
-        const int n4 = (n - head) >> 2;
-        const float4* g4 = reinterpret_cast<const float4*>(vb + head);
-        float4* l4 = reinterpret_cast<float4*>(lv + head);
-        for (int i = tid; i < n4; i += kGeoThreads) l4[i] = g4[i];
-        if (tid < head) lv[tid] = vb[tid];
-        const int tail0 = head + 4 * n4;
-        if (tid < n - tail0) lv[tail0 + tid] = vb[tail0 + tid];
-    }
+    const float* lv = LDS_VERTS ? stage_floats(lds_v, vb, n, tid) : nullptr;
     __syncthreads();
     auto coord = [&](int e) { return LDS_VERTS ? lv[e] : vb[e]; };
     const size_t nt = m.ntri;
@@ -720,42 +767,42 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
 // ------------------------------------------------------------------------------------------------
 // Phong vertex lighting (Sim3DR/lighting.py:37-62)
 // ------------------------------------------------------------------------------------------------
-// pass 1: per-image, per-axis min and max of the vertices -> scratch[b][6]
-__global__ __launch_bounds__(256) void vertex_bounds_kernel(const float* vertices, int nver, float* scratch) {
-    __shared__ float red[6][256];
-    const size_t b = blockIdx.x;
-    const float* vb = vertices + b * nver * 3;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int v = threadIdx.x; v < nver; v += 256)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float x = vb[3 * v + k];
-            mn[k] = fminf(mn[k], x);
-            mx[k] = fmaxf(mx[k], x);
-        }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = mn[k], red[3 + k][threadIdx.x] = mx[k];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
-                red[3 + k][threadIdx.x] = fmaxf(red[3 + k][threadIdx.x], red[3 + k][threadIdx.x + s]);
-            }
-        __syncthreads();
-    }
-    if (threadIdx.x < 6) scratch[b * 6 + threadIdx.x] = red[threadIdx.x][0];
-}
-
 __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
-__global__ void phong_kernel(float* light, const float* vertices, const float* normals, int nver, dad3d_light cfg,
-                             const float* bounds) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nver) return;
+// One launch: block = (vertex chunk, image). The image's vertices are staged in LDS, every block reduces the per-axis
+// min / max of the whole image itself (norm_vertices, lighting.py:9-14: exact whatever the reduction order), then lights
+// its chunk. Replaces a one-block-per-image bounds kernel (9 us, latency-bound) plus a lighting kernel.
+__global__ __launch_bounds__(kStageThreads) void phong_kernel(float* light, const float* vertices, const float* normals,
+                                                              int nver, dad3d_light cfg, int verts_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_p[];
+    __shared__ float red[6][kStageThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t b = blockIdx.y;
-    const float* bd = bounds + b * 6;
+    const float* lv = stage_floats(lds_p, vertices + b * nver * 3, nver * 3, tid);
+    __syncthreads();
+    float bd[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int u = tid; u < nver; u += kStageThreads)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = lv[3 * u + k];
+            bd[k] = fminf(bd[k], x);
+            bd[3 + k] = fmaxf(bd[3 + k], x);
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(bd[k], o);
+            bd[k] = k < 3 ? fminf(bd[k], other) : fmaxf(bd[k], other);
+        }
+        if (lane == 0) red[k][wave] = bd[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float r = red[k][0];
+        for (int wv = 1; wv < kStageThreads / 64; ++wv) r = k < 3 ? fminf(r, red[k][wv]) : fmaxf(r, red[k][wv]);
+        bd[k] = r;
+    }
     // norm_vertices (lighting.py:9-14): v -= min(0); v /= max(); v *= 2; v -= max(0)/2
     float ext[3], gmax = -INFINITY;
 #pragma unroll
@@ -763,10 +810,12 @@ __global__ void phong_kernel(float* light, const float* vertices, const float* n
         ext[k] = bd[3 + k] - bd[k];
         gmax = fmaxf(gmax, ext[k]);
     }
+    const int v_end = min(nver, ((int)blockIdx.x + 1) * verts_per_block);
+    for (int v = blockIdx.x * verts_per_block + tid; v < v_end; v += kStageThreads) {
     float vn[3], n[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float x = vertices[(b * nver + v) * 3 + k];
+        const float x = lv[3 * v + k];
         const float amax = ext[k] / gmax * 2.0f;
         vn[k] = (x - bd[k]) / gmax * 2.0f - amax / 2.0f;
         n[k] = normals[(b * nver + v) * 3 + k];
@@ -799,6 +848,7 @@ __global__ void phong_kernel(float* light, const float* vertices, const float* n
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) light[(b * nver + v) * 3 + k] = clip01(out[k]);
+    }
 }
 
 }  // namespace
@@ -806,6 +856,21 @@ __global__ void phong_kernel(float* light, const float* vertices, const float* n
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+constexpr size_t kMaxDynamicLds = 160 * 1024;
+
+// Kernels that stage a whole image per block (one block per CU: 1024 threads, 60 KB): split an image over as many
+// blocks as keeps the grid within one round of the 256 CUs, at most 8 (each block re-reads the image's vertices).
+static int staged_verts_per_block(int nver, int batch) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int chunks = std::max(1, std::min(8, cus / std::max(batch, 1)));
+    return (nver + chunks - 1) / chunks;
+}
+
 dad3d_status launch_tri_normal(const MeshDev& m, float* tri_normal, const float* vertices, int batch, int norm_flg,
                                hipStream_t s) {
     if (m.ntri == 0 || batch == 0) return DAD3D_OK;
@@ -827,8 +892,21 @@ dad3d_status launch_ver_normal(const MeshDev& m, float* ver_normal, const float*
 dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float* vertices, int batch, unsigned flags,
                                hipStream_t s) {
     if (m.nver == 0 || batch == 0) return DAD3D_OK;
-    hipLaunchKernelGGL(ver_normal_kernel<false>, dim3((m.nver + 255) / 256, batch), dim3(256), 0, s, m, ver_normal,
-                       vertices, flags);
+    const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
+    if (lds <= kMaxDynamicLds) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ver_normal_lds_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds));
+            attr_done = true;
+        }
+        const int vpb = staged_verts_per_block(m.nver, batch);
+        hipLaunchKernelGGL(ver_normal_lds_kernel, dim3((m.nver + vpb - 1) / vpb, batch), dim3(kStageThreads), lds, s, m,
+                           ver_normal, vertices, flags, vpb);
+    } else {  // a mesh too large for the LDS: gather from global memory
+        hipLaunchKernelGGL(ver_normal_kernel<false>, dim3((m.nver + 255) / 256, batch), dim3(256), 0, s, m, ver_normal,
+                           vertices, flags);
+    }
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }
@@ -892,11 +970,11 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
     {
         const dim3 ggrid((m.ntri + kGeoTrisPerBlock - 1) / kGeoTrisPerBlock, batch);
         const size_t cnt_bytes = 2 * (size_t)ntiles * sizeof(unsigned);
-        const size_t vlds = ((size_t)m.nver * 3 + 8) * sizeof(float) + cnt_bytes;
+        const size_t vlds = ((size_t)m.nver * 3 + 12) * sizeof(float) + cnt_bytes;
         if (vlds <= (size_t)kMaxLds)
             hipLaunchKernelGGL(tri_geometry_kernel<true>, ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w);
         else
-            hipLaunchKernelGGL(tri_geometry_kernel<false>, ggrid, dim3(kGeoThreads), 32 + cnt_bytes, s, m, vertices, sc, h, w);
+            hipLaunchKernelGGL(tri_geometry_kernel<false>, ggrid, dim3(kGeoThreads), 48 + cnt_bytes, s, m, vertices, sc, h, w);
         DAD3D_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(raster_queue_kernel, dim3(1), dim3(1024), 0, s, sc, (int)nlists);
@@ -912,12 +990,19 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
 }
 
 dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals, int batch,
-                          const dad3d_light& cfg, float* scratch, hipStream_t s) {
+                          const dad3d_light& cfg, hipStream_t s) {
     if (batch == 0 || m.nver == 0) return DAD3D_OK;
-    hipLaunchKernelGGL(vertex_bounds_kernel, dim3(batch), dim3(256), 0, s, vertices, m.nver, scratch);
-    DAD3D_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(phong_kernel, dim3((m.nver + 255) / 256, batch), dim3(256), 0, s, light, vertices, normals,
-                       m.nver, cfg, scratch);
+    const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
+    DAD3D_REQUIRE(lds <= kMaxDynamicLds - 1024, "phong_light: %d vertices exceed the LDS staging capacity", m.nver);
+    static bool attr_done = false;
+    if (!attr_done) {
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
+        attr_done = true;
+    }
+    const int vpb = staged_verts_per_block(m.nver, batch);
+    hipLaunchKernelGGL(phong_kernel, dim3((m.nver + vpb - 1) / vpb, batch), dim3(kStageThreads), lds, s, light, vertices,
+                       normals, m.nver, cfg, vpb);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }
