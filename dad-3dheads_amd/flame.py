@@ -168,6 +168,7 @@ class FLAMELayer(torch.nn.Module):
         self._lib = lib
         self.n_params = lib.dad3d_flame_num_params(handle)
         self.n_landmarks = 0
+        self.landmark_indices = np.zeros((0,), dtype=np.int64)
 
     def __del__(self):
         h, self._handle = getattr(self, "_handle", None), None
@@ -185,6 +186,7 @@ class FLAMELayer(torch.nn.Module):
         idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int64))
         _lib.check(self._lib.dad3d_flame_set_landmarks(self._handle, idx.ctypes.data, int(idx.size)))
         self.n_landmarks = int(idx.size)
+        self.landmark_indices = idx
 
     # ------------------------------------------------------------------------------------------
     def decode(self, params: Tensor, *, verts3d: bool = False, proj: bool = False, to_2d: bool = True,

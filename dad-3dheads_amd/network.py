@@ -1,0 +1,190 @@
+"""DAD-3DNet regressor declared for PyTorch-ROCm: the step directly in front of the decode hot path.
+
+Architecture as the reference builds it (structure only; `pytorchcv`, `torchvision` and the trained TorchScript
+checkpoint are absent here, so the ResNet-50 is hand-declared and weights are random-initialised -- throughput and
+plumbing, not accuracy):
+
+    encoder   ResNet-50 stem + 4 stages                       model_training/model/encoders.py:42-48 (StagedEncoder)
+    bifpn     3 lateral 1x1 convs, P6/P7, two BiFPN blocks    model_training/model/bifpn.py:134-163, 76-131
+    heatmap   3x3 conv, 68 channels, on the finest level      model_training/model/flame_regression.py:14-25
+    fusion    1x1 conv over [stage3, sigmoid(heatmap), P5]    flame_regression.py:28-43, then ResNet stage 4 (:91-93)
+    heads     avg-pool -> 512 -> {403 tanh*3, 10, 136 relu}   flame_regression.py:46-59, 94-99
+
+`forward` returns the reference's output dict (`landmarks_heatmap`, `3dmm_params` [B,413], `2d_landmarks` [B,68,2]).
+Inference runs channels-last in bf16 (MIOpen / hipBLASLt underneath); the 413 parameters are cast to fp32 on the way
+out because the decode computes in fp32. PyTorch is plumbing here: this file contains no custom kernels.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+OUTPUT_3DMM_PARAMS = "3dmm_params"
+OUTPUT_2D_LANDMARKS = "2d_landmarks"
+OUTPUT_LANDMARKS_HEATMAP = "landmarks_heatmap"
+
+
+def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, relu: bool = True) -> nn.Sequential:
+    layers: List[nn.Module] = [nn.Conv2d(cin, cout, k, stride, k // 2, bias=False), nn.BatchNorm2d(cout)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class Bottleneck(nn.Module):
+    """ResNet-v1.5 bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 x4, projection shortcut when the shape changes."""
+
+    def __init__(self, cin: int, width: int, stride: int):
+        super().__init__()
+        cout = 4 * width
+        self.body = nn.Sequential(_conv_bn(cin, width, 1), _conv_bn(width, width, 3, stride), _conv_bn(width, cout, 1, relu=False))
+        self.shortcut = None if (stride == 1 and cin == cout) else _conv_bn(cin, cout, 1, stride, relu=False)
+
+    def forward(self, x: Tensor) -> Tensor:
+        skip = x if self.shortcut is None else self.shortcut(x)
+        return F.relu(self.body(x) + skip, inplace=True)
+
+
+def _stage(cin: int, width: int, blocks: int, stride: int) -> nn.Sequential:
+    return nn.Sequential(*[Bottleneck(cin if i == 0 else 4 * width, width, stride if i == 0 else 1) for i in range(blocks)])
+
+
+class ResNet50Stages(nn.Module):
+    """`stages[0..4]` = stem, 256@1/4, 512@1/8, 1024@1/16, 2048@1/32 -- the split the reference's forward walks."""
+
+    channels = {"layer0": 2048, "layer1": 1024, "layer2": 512, "layer3": 256, "layer4": 64}  # model/backbone.yaml
+
+    def __init__(self):
+        super().__init__()
+        stem = nn.Sequential(_conv_bn(3, 64, 7, 2), nn.MaxPool2d(3, 2, 1))
+        self.stages = nn.ModuleList([stem, _stage(64, 64, 3, 1), _stage(256, 128, 4, 2), _stage(512, 256, 6, 2), _stage(1024, 512, 3, 2)])
+
+
+class SeparableBlock(nn.Module):
+    """depthwise 1x1 -> pointwise 1x1 -> BN(momentum .9997, eps 4e-5) -> ReLU (bifpn.py:11-43; kernel size 1 as there)."""
+
+    def __init__(self, ch: int):
+        super().__init__()
+        self.depthwise = nn.Conv2d(ch, ch, 1, groups=ch, bias=False)
+        self.pointwise = nn.Conv2d(ch, ch, 1, bias=False)
+        self.bn = nn.BatchNorm2d(ch, momentum=0.9997, eps=4e-5)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.relu(self.bn(self.pointwise(self.depthwise(x))))
+
+
+def _resize_to(x: Tensor, ref: Tensor) -> Tensor:
+    return F.interpolate(x, size=ref.shape[2:])  # nearest, like bifpn.py:105-125
+
+
+class BiFPNBlock(nn.Module):
+    """One top-down + bottom-up pass over five levels with ReLU-normalised fusion weights (+ eps AFTER the division,
+    as the reference writes it, bifpn.py:98-101)."""
+
+    def __init__(self, ch: int, eps: float = 1e-4):
+        super().__init__()
+        self.eps = eps
+        self.td = nn.ModuleList([SeparableBlock(ch) for _ in range(4)])   # P6, P5, P4, P3 (top-down order)
+        self.out = nn.ModuleList([SeparableBlock(ch) for _ in range(4)])  # P4, P5, P6, P7 (bottom-up order)
+        self.w_td = nn.Parameter(torch.ones(2, 4))
+        self.w_out = nn.Parameter(torch.ones(3, 4))
+
+    def forward(self, levels: Sequence[Tensor]) -> List[Tensor]:
+        p3, p4, p5, p6, p7 = levels
+        a = F.relu(self.w_td)
+        a = a / a.sum(0) + self.eps
+        b = F.relu(self.w_out)
+        b = b / b.sum(0) + self.eps
+        t6 = self.td[0](a[0, 0] * p6 + a[1, 0] * _resize_to(p7, p6))
+        t5 = self.td[1](a[0, 1] * p5 + a[1, 1] * _resize_to(t6, p5))
+        t4 = self.td[2](a[0, 2] * p4 + a[1, 2] * _resize_to(t5, p4))
+        o3 = self.td[3](a[0, 3] * p3 + a[1, 3] * _resize_to(t4, p3))
+        o4 = self.out[0](b[0, 0] * p4 + b[1, 0] * t4 + b[2, 0] * _resize_to(o3, p4))
+        o5 = self.out[1](b[0, 1] * p5 + b[1, 1] * t5 + b[2, 1] * _resize_to(o4, p5))
+        o6 = self.out[2](b[0, 2] * p6 + b[1, 2] * t6 + b[2, 2] * _resize_to(o5, p6))
+        o7 = self.out[3](b[0, 3] * p7 + b[1, 3] * p7 + b[2, 3] * _resize_to(o6, p7))
+        return [o3, o4, o5, o6, o7]
+
+
+class BiFPN(nn.Module):
+    def __init__(self, in_channels: Sequence[int], ch: int, num_layers: int = 2):
+        super().__init__()
+        c2, c3, c4 = in_channels
+        self.lateral = nn.ModuleList([nn.Conv2d(c2, ch, 1), nn.Conv2d(c3, ch, 1), nn.Conv2d(c4, ch, 1)])
+        self.p6 = nn.Conv2d(c4, ch, 3, 2, 1)
+        self.p7 = nn.Sequential(nn.Conv2d(ch, ch, 3, 2, 1), nn.BatchNorm2d(ch, momentum=0.9997, eps=4e-5), nn.ReLU())
+        self.blocks = nn.ModuleList([BiFPNBlock(ch) for _ in range(num_layers)])
+
+    def forward(self, feats: Sequence[Tensor]) -> List[Tensor]:
+        c2, c3, c4 = feats
+        p6 = self.p6(c4)
+        levels = [self.lateral[0](c2), self.lateral[1](c3), self.lateral[2](c4), p6, self.p7(p6)]
+        for blk in self.blocks:
+            levels = blk(levels)
+        return levels
+
+
+class RegressionHead(nn.Module):
+    def __init__(self, cin: int, cout: int, hidden: int = 512, dropout: float = 0.3):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(cin, hidden), nn.ReLU(inplace=True), nn.Dropout(dropout), nn.Linear(hidden, cout))
+
+    def forward(self, fmap: Tensor) -> Tensor:
+        return self.mlp(fmap.mean(dim=(2, 3)))
+
+
+class DAD3DNet(nn.Module):
+    """FlameRegression (flame_regression.py:62-105) with the resnet50 config of config/model/resnet_regression.yaml."""
+
+    def __init__(self, num_landmarks: int = 68, num_filters: int = 256, limit_value: float = 3.0, seed: int = 0):
+        super().__init__()
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        try:
+            self.encoder = ResNet50Stages()
+            ch = ResNet50Stages.channels
+            self.bifpn = BiFPN([ch["layer3"], ch["layer2"], ch["layer1"]], num_filters)
+            self.heatmap = nn.Conv2d(num_filters, num_landmarks, 3, padding=1)
+            nn.init.zeros_(self.heatmap.bias)
+            self.fusion = nn.Conv2d(num_filters + num_landmarks + ch["layer1"], ch["layer1"], 1)
+            self.shape = RegressionHead(ch["layer0"], 403)   # 300 shape + 100 expression + 3 jaw
+            self.pose = RegressionHead(ch["layer0"], 10)     # 6-DoF rotation, translation, scale
+            self.landmarks = RegressionHead(ch["layer0"], 2 * num_landmarks)
+        finally:
+            torch.random.set_rng_state(gen_state)
+        self.limit_value = limit_value
+
+    def forward(self, x: Tensor) -> Dict[str, Tensor]:
+        stages = self.encoder.stages
+        feats = []
+        for st in stages[:4]:
+            x = st(x)
+            feats.append(x)
+        levels = self.bifpn(feats[1:])
+        heatmap = self.heatmap(levels[0])
+        hm = F.interpolate(heatmap, size=x.shape[2:], mode="bilinear", align_corners=True).sigmoid()
+        fused = self.fusion(torch.cat([x, hm, levels[2]], dim=1)) * x
+        top = stages[4](fused)
+        shape = torch.tanh(self.shape(top)) * self.limit_value
+        lmk = F.relu(self.landmarks(top)).reshape(x.shape[0], -1, 2)
+        return {OUTPUT_LANDMARKS_HEATMAP: heatmap, OUTPUT_3DMM_PARAMS: torch.cat([shape, self.pose(top)], dim=1),
+                OUTPUT_2D_LANDMARKS: lmk}
+
+
+class InferenceNet(nn.Module):
+    """`DAD3DNet` frozen for serving: eval mode, channels-last, reduced-precision autocast; fp32 parameters out."""
+
+    def __init__(self, net: nn.Module, dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        self.net = net.eval().to(memory_format=torch.channels_last)
+        self.dtype = dtype
+
+    @torch.no_grad()
+    def forward(self, x: Tensor) -> Dict[str, Tensor]:
+        x = x.contiguous(memory_format=torch.channels_last)
+        with torch.autocast(device_type=x.device.type, dtype=self.dtype, enabled=self.dtype != torch.float32):
+            out = self.net(x)
+        return {k: v.float() for k, v in out.items()}

@@ -82,6 +82,15 @@ class FaceMeshPredictor:
 
         return cls(config=load_default_config(), **kwargs)
 
+    @classmethod
+    def random_init(cls, dtype: torch.dtype = torch.bfloat16, seed: int = 0, **kwargs):
+        """DAD-3DNet architecture declared in `network.py` with seeded random weights (no checkpoint offline):
+        the real compute and memory footprint of the front half for throughput and plumbing tests."""
+        from .config import load_default_config
+        from .network import DAD3DNet, InferenceNet
+
+        return cls(config=load_default_config(), model=InferenceNet(DAD3DNet(seed=seed), dtype), **kwargs)
+
     # -- preprocess (predictor.py:86-95,195-203) ---------------------------------------------------------
     def _geometry(self, hw: Tuple[int, int]) -> Tuple[List[int], float, Tuple[int, int]]:
         h, w = hw
@@ -131,6 +140,42 @@ class FaceMeshPredictor:
 
     def __call__(self, x: Any) -> Dict[str, Any]:
         res = self.predict_batch([x])[0]
+        return res
+
+    def predict_tensor(self, images: torch.Tensor, landmarks_px: bool = True) -> Dict[str, torch.Tensor]:
+        """Device-resident batch entry: uint8 RGB `[B, H, W, 3]` on this GPU, all images of one size -> device tensors
+        `3dmm_params [B,413]`, `3d_vertices [B,5023,3]`, `projected_vertices [B,5023,2]`, `points [B,68,2]` int32
+        and, when the head mesh was built with a landmark list, `landmarks [B,n,2]` int32. Nothing is copied to the
+        host and nothing synchronises: normalisation, CNN, re-adjustment kernel and the fused decode are queued on
+        the current stream (the reference does `.cpu()` after the CNN, predictor.py:104, then decodes twice on the CPU)."""
+        assert images.ndim == 4 and images.shape[-1] == 3 and images.dtype == torch.uint8 and images.is_cuda
+        b, h, w = images.shape[:3]
+        pads, scale, (nh, nw) = self._geometry((h, w))
+        x = images.permute(0, 3, 1, 2).float()
+        if (nh, nw) != (h, w):
+            x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False).round_().clamp_(0, 255)
+        s = self._img_size
+        if (nh, nw) != (s, s):
+            x = F.pad(x, (pads[2], s - nw - pads[2], pads[0], s - nh - pads[0]), value=0.0)
+        mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1) * 255.0
+        std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1) * 255.0
+        out = self.process((x - mean) / std)
+        params = out[OUTPUT_3DMM_PARAMS].detach().to(torch.float32).contiguous().clone()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # one (pad_left, pad_top, scale) triple for the whole batch: pads_scale == NULL
+        _lib.check(self._lib.dad3d_flame_readjust_params(self.head_mesh.flame._handle, params.data_ptr(), b, None,
+                                                         float(pads[2]), float(pads[0]), float(scale), stream))
+        want_lmk = landmarks_px and self.head_mesh.flame.n_landmarks > 0
+        dec = self.head_mesh.decode(params, verts3d=True, proj=True, to_2d=True, landmarks=False, landmarks_px=want_lmk,
+                                    mutate=True)
+        res = {"3dmm_params": params, "3d_vertices": dec["verts3d"], "projected_vertices": dec["proj"]}
+        if want_lmk:
+            res["landmarks"] = dec["lmk_px"]
+        if OUTPUT_2D_LANDMARKS in out:  # predictor.py:147-152 on the device
+            # numpy promotes to float64 at the integer pad subtraction; same here so `astype(int)` truncates alike
+            pts = (out[OUTPUT_2D_LANDMARKS].detach().float() * 256.0).clamp_(0, self._img_size).double()
+            pts = (pts - torch.tensor([pads[2], pads[0]], device=self.device, dtype=torch.float64)) / scale
+            res["points"] = pts.to(torch.int32)
         return res
 
     def predict_batch(self, images: Sequence[np.ndarray], device_outputs: bool = False) -> List[Dict[str, Any]]:

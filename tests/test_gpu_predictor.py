@@ -94,3 +94,58 @@ def test_missing_checkpoint_is_a_loud_error(flame_model, tmp_path, monkeypatch):
     monkeypatch.setenv("HOME", str(tmp_path))
     with pytest.raises(FileNotFoundError, match="no network"):
         FaceMeshPredictor(load_default_config(), cuda_id=0, flame_model=flame_model)
+
+
+# ---- DAD-3DNet front half declared for PyTorch-ROCm ------------------------------------------------
+@pytest.fixture(scope="module")
+def net_predictor(flame_model):
+    from dad_3dheads_amd import landmarks
+
+    return FaceMeshPredictor.random_init(cuda_id=0, flame_model=flame_model, landmarks=landmarks.canonical("445"))
+
+
+def test_network_output_contract(net_predictor):
+    x = torch.randn(3, 3, 256, 256, device="cuda")
+    out = net_predictor.process(x)
+    assert out["3dmm_params"].shape == (3, 413) and out["3dmm_params"].dtype == torch.float32
+    assert out["2d_landmarks"].shape == (3, 68, 2) and (out["2d_landmarks"] >= 0).all()
+    assert out["landmarks_heatmap"].shape == (3, 68, 64, 64)
+    assert out["3dmm_params"][:, :403].abs().max() <= 3.0  # tanh * limit_value (flame_regression.py:94)
+
+
+@pytest.mark.parametrize("hw", [(256, 256), (320, 240)])
+def test_device_resident_batch_matches_reference_postprocess(net_predictor, flame_consts, hw, monkeypatch):
+    """predict_tensor: nothing leaves the GPU; from the SAME CNN output the reference's CPU post-processing
+    (re-adjust, two decodes, astype(int) gather) must agree."""
+    g = torch.Generator().manual_seed(5)
+    images = torch.randint(0, 255, (4, hw[0], hw[1], 3), dtype=torch.uint8, generator=g).cuda()
+    seen = {}
+    real_process = net_predictor.process
+
+    def recording_process(x):  # keep the network output this very call produced (reduced-precision convolutions need
+        seen["x"], seen["out"] = x, real_process(x)  # not be bit-reproducible between two calls)
+        return seen["out"]
+
+    monkeypatch.setattr(net_predictor, "process", recording_process)
+    res = net_predictor.predict_tensor(images)
+    monkeypatch.undo()
+    assert all(v.is_cuda for v in res.values())
+    assert res["points"].shape == (4, 68, 2) and res["points"].dtype == torch.int32
+    assert res["landmarks"].shape == (4, 445, 2) and res["landmarks"].dtype == torch.int32
+    # the batched device-side normalisation equals the per-image preprocess of the single-image path
+    x = torch.cat([net_predictor.preprocess(im, {}) for im in images.cpu().numpy()])
+    assert torch.allclose(seen["x"], x, atol=1e-5)
+    params = seen["out"]["3dmm_params"].detach().cpu().clone()
+    lm68 = seen["out"]["2d_landmarks"].detach().cpu().numpy() * 256.0
+    pads, scale = flame_ref.get_paddings(hw)
+    params = flame_ref.readjust_3dmm(params, pads, scale)
+    v3d = flame_ref.vertices_3d(flame_consts, params)
+    proj = flame_ref.reprojected_vertices(flame_consts, params, to_2d=True)
+    assert x.shape == (4, 3, 256, 256)
+    pts = ((lm68.clip(min=0, max=256) - np.array([[pads[2], pads[0]]])) / scale).astype(int)
+    assert np.array_equal(res["points"].cpu().numpy(), pts)
+    assert (res["3dmm_params"].cpu() - params).abs().max() < 1e-5
+    assert (res["3d_vertices"].cpu() - v3d).abs().max() < 5e-6
+    assert (res["projected_vertices"].cpu() - proj).abs().max() < 2e-3
+    idx = torch.from_numpy(np.asarray(net_predictor.head_mesh.flame.landmark_indices)).long()
+    assert torch.equal(res["landmarks"].cpu(), res["projected_vertices"].cpu()[:, idx, :].to(torch.int32))

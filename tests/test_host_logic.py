@@ -89,3 +89,25 @@ def test_flame_pickle_loader_without_chumpy(tmp_path, flame_model):
     assert np.array_equal(m.J_regressor, flame_model.J_regressor[:, :7])
     with pytest.raises(FileNotFoundError, match="flame.pkl"):
         flame.get_flame_model(str(tmp_path / "nope.pkl"))
+
+
+def test_dad3dnet_declaration_matches_the_reference_output_contract():
+    """network.py: output dict of flame_regression.py:100-104 with the resnet50 config shapes, on CPU."""
+    import torch
+
+    from dad_3dheads_amd.network import DAD3DNet, InferenceNet
+
+    net = DAD3DNet(seed=0).eval()  # eval: the stage walk below must not move the BatchNorm statistics
+    assert 32e6 < sum(p.numel() for p in net.parameters()) < 34e6  # ResNet-50 23.5 M + fusion + BiFPN + three heads
+    x = torch.zeros(1, 3, 256, 256)
+    feats, f = [], x
+    for st in net.encoder.stages:
+        f = st(f)
+        feats.append(tuple(f.shape[1:]))
+    assert feats == [(64, 64, 64), (256, 64, 64), (512, 32, 32), (1024, 16, 16), (2048, 8, 8)]
+    out = InferenceNet(net, torch.float32)(torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)))
+    assert out["3dmm_params"].shape == (1, 413) and out["2d_landmarks"].shape == (1, 68, 2)
+    assert out["landmarks_heatmap"].shape == (1, 68, 64, 64)
+    assert out["3dmm_params"][:, :403].abs().max() <= 3.0 and (out["2d_landmarks"] >= 0).all()
+    again = InferenceNet(DAD3DNet(seed=0), torch.float32)(torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)))
+    assert torch.equal(out["3dmm_params"], again["3dmm_params"])  # seeded initialisation
