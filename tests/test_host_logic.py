@@ -111,3 +111,52 @@ def test_dad3dnet_declaration_matches_the_reference_output_contract():
     assert out["3dmm_params"][:, :403].abs().max() <= 3.0 and (out["2d_landmarks"] >= 0).all()
     again = InferenceNet(DAD3DNet(seed=0), torch.float32)(torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)))
     assert torch.equal(out["3dmm_params"], again["3dmm_params"])  # seeded initialisation
+
+
+def test_obj_and_json_writers_produce_the_reference_bytes(tmp_path):
+    """writers.py vs the formatting statements of demo_utils.py:106-153 restated line by line."""
+    import json
+
+    import torch
+
+    from dad_3dheads_amd import writers
+    from dad_3dheads_amd.flame import FLAME_CONSTS
+
+    rng = np.random.default_rng(0)
+    verts = (rng.standard_normal((50, 3)) * 0.1).astype(np.float32)
+    verts[0] = [0.0, -0.0, 1e-9]
+    faces = rng.integers(0, 50, (20, 3))
+    v, f = writers.get_mesh({"3d_vertices": torch.from_numpy(verts)}, faces)
+    assert f.dtype == np.float64 and np.array_equal(f, faces + 1.0)
+    expected = "".join("v %.8f %.8f %.8f\n" % tuple(row) for row in v) + "".join("f %d %d %d\n" % tuple(row) for row in f)
+    path = tmp_path / "m.obj"
+    writers.MeshSaver()(( v, f), str(path))
+    assert path.read_text() == expected and writers.obj_text(v, f) == expected
+    batch = torch.from_numpy(np.stack([verts, verts * 2]))
+    paths = [str(tmp_path / "a.obj"), str(tmp_path / "b.obj")]
+    writers.save_obj_batch(batch, faces, paths)
+    assert open(paths[0]).read() == expected and open(paths[1]).read().startswith("v %.8f %.8f %.8f\n" % tuple(verts[0] * 2))
+    params = torch.arange(2 * 413, dtype=torch.float32).reshape(2, 413)
+    d = writers.get_flame_params({"3dmm_params": params})
+    assert list(d) == ["shape", "expression", "rotation", "translation", "scale", "jaw", "eyeballs", "neck"]
+    assert d["shape"] == list(map(float, range(300))) and d["jaw"] == [400.0, 401.0, 402.0] and d["rotation"] == [403.0 + i for i in range(6)]
+    assert d["eyeballs"] == [] and d["scale"] == [412.0] and sum(FLAME_CONSTS.values()) == 413
+    assert writers.flame_params_batch(params)[0] == d and writers.flame_params_batch(params)[1]["scale"] == [825.0]
+    jp = tmp_path / "p.json"
+    writers.JsonSaver()(d, str(jp))
+    assert json.loads(jp.read_text()) == d
+    assert writers.get_output_path("/x/y/1.jpeg", "out", "head_mesh", ".obj") == "out/1_head_mesh.obj"
+
+
+def test_ncc_color_codes():
+    from dad_3dheads_amd.pncc import compute_ncc_color_codes
+
+    t = np.array([[1.0, -2.0, 3.0], [2.0, -1.0, 5.0], [4.0, -4.0, 4.0]])
+    c = compute_ncc_color_codes(t, np.array([0, 1]))
+    # `initial=0` (pncc_estimator.py:54-55): zero joins the subset's min and max
+    lo, hi = np.array([[0.0, -2.0, 0.0]]), np.array([[2.0, 0.0, 5.0]])
+    assert np.array_equal(c, (t - lo) / (hi - lo))
+    with pytest.raises(ValueError):
+        compute_ncc_color_codes(t.tolist())
+    with pytest.raises(ValueError):
+        compute_ncc_color_codes(t[:, :2])
