@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m
 //                        is much heavier than the rest (eyes, lips and ears of a head mesh put 3000+ triangles
 //                        into one tile while most tiles hold a few hundred).
 //   raster_kernel        persistent workgroups pull items. Per item, keys in LDS: (A) counting-sort the tile list by
-//                        box area into 9 classes; a class-c triangle gets 2^max(c-2,0) lanes, so every lane of a
+//                        box area into 12 classes; a class-c triangle gets 2^max(c-2,0) lanes, so every lane of a
 //                        wave has at most 8 pixel tests to do whatever the triangle size (one-lane-per-triangle
 //                        left most lanes idle). (B) the lanes ds_max_u64 their fragments. (C) every pixel is shaded
 //                        once from the record of its winning triangle and merged into the image as whole dwords.
@@ -250,6 +250,9 @@ struct RasterScratch {
     int tiles_x, tiles_y;
 };
 
+#ifndef DAD3D_K1_ABLATE  // diagnostics only (tools/k1_ablate.sh): 1 no LDS binning atomics, 2 no list writes, 4 no records
+#define DAD3D_K1_ABLATE 0
+#endif
 template <bool LDS_VERTS>
 __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, const float* vertices, RasterScratch sc,
                                                                    int h, int w) {
@@ -285,11 +288,15 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
         box[k] = make_uint2((unsigned)bx0 | ((unsigned)bx1 << 16), (unsigned)by0 | ((unsigned)by1 << 16));
         const TriSetup ts = tri_setup(x0, y0, x1, y1, x2, y2);
         float4* rp = sc.rec + (b * nt + f) * kRecF4;
-        rp[0] = make_float4(ts.x0, ts.y0, ts.ax, ts.ay);
-        rp[1] = make_float4(ts.bx, ts.by, ts.d00, ts.d01);
-        rp[2] = make_float4(ts.d11, ts.inv, z0, z1);
-        rp[3] = make_float4(z2, __uint_as_float(box[k].x), __uint_as_float(box[k].y), 0.0f);
-        if (bx0 <= bx1)
+        // records are only ever read through the tile lists: an off-screen triangle (a fifth of a head that fills
+        // the frame) is in none and needs none -- the record stream is the largest cost of this kernel
+        if ((bx0 <= bx1 && !(DAD3D_K1_ABLATE & 4)) || ts.inv == 12345.0f) {
+            rp[0] = make_float4(ts.x0, ts.y0, ts.ax, ts.ay);
+            rp[1] = make_float4(ts.bx, ts.by, ts.d00, ts.d01);
+            rp[2] = make_float4(ts.d11, ts.inv, z0, z1);
+            rp[3] = make_float4(z2, __uint_as_float(box[k].x), __uint_as_float(box[k].y), 0.0f);
+        }
+        if (bx0 <= bx1 && !(DAD3D_K1_ABLATE & 1))
             for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
                 for (int tx = bx0 >> kTileShift; tx <= bx1 >> kTileShift; ++tx) {
                     const int cw = min(bx1, tx * kTile + kTile - 1) - max(bx0, tx * kTile) + 1;
@@ -302,6 +309,10 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     // reserve this block's share of every tile list; cnt[] becomes the write cursor
     for (int t = tid; t < ntiles; t += kGeoThreads) {
         const unsigned c = cnt[t];
+        if (DAD3D_K1_ABLATE & 2) {
+            cnt[t] = 0;
+            continue;
+        }
         cnt[t] = c ? atomicAdd(&sc.counts[b * ntiles + t], c) : 0u;
         if (c) atomicAdd(&sc.counts[(gridDim.y + b) * ntiles + t], asum[t]);
     }
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     for (int k = 0; k < kGeoPerThread; ++k) {
         const int f = blockIdx.x * kGeoTrisPerBlock + k * kGeoThreads + tid;
         const int bx0 = box[k].x & 0xffff, bx1 = box[k].x >> 16, by0 = box[k].y & 0xffff, by1 = box[k].y >> 16;
-        if (bx0 > bx1) continue;  // empty box: in no list
+        if (bx0 > bx1 || (DAD3D_K1_ABLATE & 3)) continue;  // empty box: in no list
         for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
             for (int tx = bx0 >> kTileShift; tx <= bx1 >> kTileShift; ++tx) {
                 const int t = ty * sc.tiles_x + tx;
