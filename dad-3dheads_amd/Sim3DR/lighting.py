@@ -56,8 +56,7 @@ class RenderPipeline(object):
         dev = mesh.torch_device
         v = torch.from_numpy(np.ascontiguousarray(vertices, dtype=np.float32)).to(dev)[None]
         img = torch.from_numpy(bg).to(dev)[None].contiguous()
-        normals = mesh.get_normal(v)
-        light = mesh.phong_light(v, normals, **self._light_kwargs())
+        light = mesh.phong_light(v, None, **self._light_kwargs())  # vertex normals + Phong terms in one launch
         if texture is None:
             colors = light
         else:

@@ -108,22 +108,28 @@ class Mesh:
         return depth, tri_buf, bary
 
     # -- lighting ----------------------------------------------------------------------------------
-    def phong_light(self, vertices: Tensor, normals: Tensor, ambient: float = 0.3, directional: float = 0.6,
+    def phong_light(self, vertices: Tensor, normals: Optional[Tensor] = None, ambient: float = 0.3, directional: float = 0.6,
                     specular: float = 0.1, specular_exp: float = 5, color_ambient: Sequence[float] = (1, 1, 1),
                     color_directional: Sequence[float] = (1, 1, 1), light_pos: Sequence[float] = (0, 0, 5),
-                    view_pos: Sequence[float] = (0, 0, 5)) -> Tensor:
+                    view_pos: Sequence[float] = (0, 0, 5), normals_out: Optional[Tensor] = None) -> Tensor:
+        """Per-vertex Phong light (lighting.py:41-62). `normals=None`: the vertex normals are computed in the same
+        launch (and stored into `normals_out` when given) -- RenderPipeline's `_get_normal` + lighting in one pass."""
         v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
-        n = _chk(normals, torch.float32, 3, "normals", self.torch_device)
         cfg = _lib.LightC(float(ambient), float(directional), float(specular), float(specular_exp),
                           (C.c_float * 3)(*color_ambient), (C.c_float * 3)(*color_directional),
                           (C.c_float * 3)(*light_pos), (C.c_float * 3)(*view_pos))
         out = torch.empty_like(v)
+        if normals is None:
+            n_out = None if normals_out is None else _chk(normals_out, torch.float32, 3, "normals_out", self.torch_device)
+            _lib.check(self._lib.dad3d_mesh_normal_phong_light(self._handle, out.data_ptr(), None if n_out is None else n_out.data_ptr(),
+                                                               v.data_ptr(), v.shape[0], C.byref(cfg), self._stream()))
+            return out
+        n = _chk(normals, torch.float32, 3, "normals", self.torch_device)
         _lib.check(self._lib.dad3d_mesh_phong_light(self._handle, out.data_ptr(), v.data_ptr(), n.data_ptr(), v.shape[0],
                                                     C.byref(cfg), self._stream()))
         return out
 
     def render(self, vertices: Tensor, bg: Tensor, **light_kwargs) -> Tensor:
-        """RenderPipeline.__call__ (lighting.py:37-71, texture=None) for a batch: normals -> Phong -> raster."""
-        normals = self.get_normal(vertices)
-        light = self.phong_light(vertices, normals, **light_kwargs)
+        """RenderPipeline.__call__ (lighting.py:37-71, texture=None) for a batch: normals + Phong (one launch) -> raster."""
+        light = self.phong_light(vertices, None, **light_kwargs)
         return self.rasterize(vertices, light, bg)

@@ -528,7 +528,16 @@ dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* ve
     if (batch == 0 || m->nver == 0) return DAD3D_OK;
     DAD3D_REQUIRE(light && vertices && normals, "dad3d_mesh_phong_light: null buffer");
     DeviceGuard guard(m->device);
-    return launch_phong(m->dev(), light, vertices, normals, batch, *cfg, static_cast<hipStream_t>(stream));
+    return launch_phong(m->dev(), light, vertices, normals, nullptr, batch, *cfg, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* ver_normal, const float* vertices,
+                                           int batch, const dad3d_light* cfg, void* stream) {
+    DAD3D_REQUIRE(m && cfg && batch >= 0, "dad3d_mesh_normal_phong_light: bad argument");
+    if (batch == 0 || m->nver == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(light && vertices, "dad3d_mesh_normal_phong_light: null buffer");
+    DeviceGuard guard(m->device);
+    return launch_phong(m->dev(), light, vertices, nullptr, ver_normal, batch, *cfg, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -126,7 +126,7 @@ dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int
 dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image, const float* vertices,
                               const float* colors, float* depth, int32_t* tri_buf, float* bary, int batch, int h,
                               int w, int c, int reverse, int mode, hipStream_t s);
-dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals, int batch,
-                          const dad3d_light& cfg, hipStream_t s);
+dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals,
+                          float* normals_out, int batch, const dad3d_light& cfg, hipStream_t s);
 
 }  // namespace dad3d

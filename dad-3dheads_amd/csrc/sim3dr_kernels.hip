@@ -151,33 +151,52 @@ __global__ void ver_normal_kernel(MeshDev m, float* ver_normal, const float* src
 // the three corner indices of every incident face (adj_tri), so a vertex costs one 16-byte load per incident face and
 // nine LDS reads instead of thirteen scattered global loads. Same arithmetic and summation order as above.
 constexpr int kAdjAhead = 8;  // incident faces requested together (FLAME: valence <= 8 for 99 % of the vertices)
+// The incidence row of a vertex, requested in one go: two dependent round trips (row bounds, then entries) that the
+// kernels below overlap with the staging of the vertices or with the arithmetic of the previous vertex.
+struct AdjRow {
+    int e0, e1;
+    int4 t[kAdjAhead];
+};
+__device__ __forceinline__ AdjRow load_adj_row(const MeshDev& m, int v, bool live) {
+    AdjRow r;
+    r.e0 = live ? m.adj_ptr[v] : 0;
+    r.e1 = live ? m.adj_ptr[v + 1] : 0;
+#pragma unroll
+    for (int j = 0; j < kAdjAhead; ++j) r.t[j] = (r.e0 + j < r.e1) ? m.adj_tri[r.e0 + j] : make_int4(0, 0, 0, 0);
+    return r;
+}
+// acc += sum of the cross products of the faces around the vertex, ascending face order; lv = the image's vertices in LDS
+__device__ __forceinline__ void add_incident_faces(const MeshDev& m, const float* lv, const AdjRow& r, float acc[3]) {
+    auto add_face = [&](const int4& f) {
+        float n[3];
+        face_cross(lv, f.x, f.y, f.z, n);
+        acc[0] += n[0];
+        acc[1] += n[1];
+        acc[2] += n[2];
+    };
+#pragma unroll
+    for (int j = 0; j < kAdjAhead; ++j)
+        if (r.e0 + j < r.e1) add_face(r.t[j]);
+    for (int e = r.e0 + kAdjAhead; e < r.e1; ++e) add_face(m.adj_tri[e]);
+}
+
 __global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m, float* ver_normal, const float* vertices,
                                                                        unsigned flags, int verts_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds_n[];
     const int tid = threadIdx.x;
     const size_t b = blockIdx.y;
+    const int v_end = min(m.nver, ((int)blockIdx.x + 1) * verts_per_block);
+    const int v0 = blockIdx.x * verts_per_block + tid;
+    AdjRow row = load_adj_row(m, v0, v0 < v_end);  // in flight while the vertices are staged
     const float* lv = stage_floats(lds_n, vertices + b * m.nver * 3, m.nver * 3, tid);
     __syncthreads();
-    const int v_end = min(m.nver, ((int)blockIdx.x + 1) * verts_per_block);
-    for (int v = blockIdx.x * verts_per_block + tid; v < v_end; v += kStageThreads) {
-        const int e0 = m.adj_ptr[v], e1 = m.adj_ptr[v + 1];
-        int4 t[kAdjAhead];  // one round trip for the whole row instead of one per incident face
-#pragma unroll
-        for (int j = 0; j < kAdjAhead; ++j) t[j] = (e0 + j < e1) ? m.adj_tri[e0 + j] : make_int4(0, 0, 0, 0);
+    for (int v = v0; v < v_end; v += kStageThreads) {
+        const AdjRow cur = row;
+        row = load_adj_row(m, v + kStageThreads, v + kStageThreads < v_end);
         float* d = ver_normal + (b * m.nver + v) * 3;
         float acc[3] = {0.0f, 0.0f, 0.0f};
         if (flags & DAD3D_NORMAL_ACCUMULATE) acc[0] = d[0], acc[1] = d[1], acc[2] = d[2];
-        auto add_face = [&](const int4& f) {
-            float n[3];
-            face_cross(lv, f.x, f.y, f.z, n);
-            acc[0] += n[0];
-            acc[1] += n[1];
-            acc[2] += n[2];
-        };
-#pragma unroll
-        for (int j = 0; j < kAdjAhead; ++j)
-            if (e0 + j < e1) add_face(t[j]);
-        for (int e = e0 + kAdjAhead; e < e1; ++e) add_face(m.adj_tri[e]);
+        add_incident_faces(m, lv, cur, acc);
         unit3(acc);
         d[0] = acc[0];
         d[1] = acc[1];
@@ -783,12 +802,20 @@ __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 
 // One launch: block = (vertex chunk, image). The image's vertices are staged in LDS, every block reduces the per-axis
 // min / max of the whole image itself (norm_vertices, lighting.py:9-14: exact whatever the reduction order), then lights
 // its chunk. Replaces a one-block-per-image bounds kernel (9 us, latency-bound) plus a lighting kernel.
-__global__ __launch_bounds__(kStageThreads) void phong_kernel(float* light, const float* vertices, const float* normals,
-                                                              int nver, dad3d_light cfg, int verts_per_block) {
+// FUSE_NORMALS: the vertex normals are computed here from the staged vertices (_get_normal on a zeroed buffer, as
+// RenderPipeline does, lighting.py:64-66) instead of being read back; `normals_out` (optional) receives them.
+template <bool FUSE_NORMALS>
+__global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* light, const float* vertices,
+                                                              const float* normals, float* normals_out, int nver,
+                                                              dad3d_light cfg, int verts_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds_p[];
     __shared__ float red[6][kStageThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t b = blockIdx.y;
+    const int v_end = min(nver, ((int)blockIdx.x + 1) * verts_per_block);
+    const int v0 = blockIdx.x * verts_per_block + tid;
+    AdjRow row;
+    if (FUSE_NORMALS) row = load_adj_row(m, v0, v0 < v_end);  // in flight while the vertices are staged
     const float* lv = stage_floats(lds_p, vertices + b * nver * 3, nver * 3, tid);
     __syncthreads();
     float bd[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -821,15 +848,26 @@ __global__ __launch_bounds__(kStageThreads) void phong_kernel(float* light, cons
         ext[k] = bd[3 + k] - bd[k];
         gmax = fmaxf(gmax, ext[k]);
     }
-    const int v_end = min(nver, ((int)blockIdx.x + 1) * verts_per_block);
-    for (int v = blockIdx.x * verts_per_block + tid; v < v_end; v += kStageThreads) {
+    for (int v = v0; v < v_end; v += kStageThreads) {
+    AdjRow cur;
+    if (FUSE_NORMALS) {
+        cur = row;
+        row = load_adj_row(m, v + kStageThreads, v + kStageThreads < v_end);
+    }
     float vn[3], n[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float x = lv[3 * v + k];
         const float amax = ext[k] / gmax * 2.0f;
         vn[k] = (x - bd[k]) / gmax * 2.0f - amax / 2.0f;
-        n[k] = normals[(b * nver + v) * 3 + k];
+        n[k] = FUSE_NORMALS ? 0.0f : normals[(b * nver + v) * 3 + k];
+    }
+    if (FUSE_NORMALS) {
+        add_incident_faces(m, lv, cur, n);
+        unit3(n);
+        if (normals_out)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) normals_out[(b * nver + v) * 3 + k] = n[k];
     }
     float out[3] = {0.0f, 0.0f, 0.0f};
     if (cfg.intensity_ambient > 0.0f)
@@ -1000,20 +1038,28 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
     return DAD3D_OK;
 }
 
-dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals, int batch,
-                          const dad3d_light& cfg, hipStream_t s) {
+// normals == nullptr: compute them in the same launch (normals_out optional); else light from the given normals
+dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals,
+                          float* normals_out, int batch, const dad3d_light& cfg, hipStream_t s) {
     if (batch == 0 || m.nver == 0) return DAD3D_OK;
     const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
     DAD3D_REQUIRE(lds <= kMaxDynamicLds - 1024, "phong_light: %d vertices exceed the LDS staging capacity", m.nver);
     static bool attr_done = false;
     if (!attr_done) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
         attr_done = true;
     }
     const int vpb = staged_verts_per_block(m.nver, batch);
-    hipLaunchKernelGGL(phong_kernel, dim3((m.nver + vpb - 1) / vpb, batch), dim3(kStageThreads), lds, s, light, vertices,
-                       normals, m.nver, cfg, vpb);
+    const dim3 grid((m.nver + vpb - 1) / vpb, batch);
+    if (normals)
+        hipLaunchKernelGGL(phong_kernel<false>, grid, dim3(kStageThreads), lds, s, m, light, vertices, normals, nullptr,
+                           m.nver, cfg, vpb);
+    else
+        hipLaunchKernelGGL(phong_kernel<true>, grid, dim3(kStageThreads), lds, s, m, light, vertices, nullptr, normals_out,
+                           m.nver, cfg, vpb);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

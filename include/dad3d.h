@@ -169,6 +169,10 @@ typedef struct dad3d_light {
 } dad3d_light;
 dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,
                                     int batch, const dad3d_light* cfg, void* stream);
+/* RenderPipeline's first two steps in ONE launch (lighting.py:64-67: `_get_normal` on a zeroed buffer, then the Phong
+ * terms): light [B,nver,3] from the vertices alone; `ver_normal` [B,nver,3] receives the normals, or NULL. */
+dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* ver_normal, const float* vertices,
+                                           int batch, const dad3d_light* cfg, void* stream);
 /* Diagnostics: DEVICE buffer of [B * tiles][8 waves][16] uint64 that every wave of the raster kernel fills with
  * 100 MHz wall-clock stamps at its phase boundaries (slots 0-6: start, list sorted, fragments done, after barrier,
  * shaded, after barrier, end; 7: triangles in the tile list; 8-11 / 12-15: wave steps, ticks waiting for records,

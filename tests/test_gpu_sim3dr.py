@@ -133,8 +133,15 @@ def test_render_pipeline_matches_numpy_lighting(static, decode_golden, port_orac
     img = Sim3DR.RenderPipeline()(verts.copy(), faces, np.zeros((256, 256, 3), np.uint8))
     mesh = Mesh(faces, 5023, device=0)
     dv = torch.from_numpy(verts).cuda()[None]
-    light = mesh.phong_light(dv, mesh.get_normal(dv))[0].cpu().numpy()
+    normals = mesh.get_normal(dv)
+    light = mesh.phong_light(dv, normals)[0].cpu().numpy()
     assert np.abs(light - ref_light).max() < 2e-5  # float pow / normalisation differ by rounding only
+    # the one-launch variant (normals computed inside) is the same arithmetic: identical bits, normals included
+    n_out = torch.empty_like(dv)
+    fused = mesh.phong_light(dv, None, normals_out=n_out)
+    assert torch.equal(n_out, normals) and np.array_equal(fused[0].cpu().numpy(), light)
+    b8 = dv.expand(8, -1, -1).contiguous() * torch.linspace(0.9, 1.1, 8, device="cuda")[:, None, None]
+    assert torch.equal(mesh.phong_light(b8, None), mesh.phong_light(b8, mesh.get_normal(b8)))
     diff = np.abs(img.astype(int) - ref_img.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02  # coverage identical, colours within one LSB
     assert np.array_equal(img.sum(-1) > 0, ref_img.sum(-1) > 0)

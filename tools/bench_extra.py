@@ -66,13 +66,13 @@ def main():
     ncc = ((tmpl - tmpl.min(0).values) / (tmpl.max(0).values - tmpl.min(0).values)).float()[None].expand(B, -1, -1).contiguous()
     t_norm = gpu_time(lambda: mesh.get_normal(verts, out=normals))
     t_light = gpu_time(lambda: mesh.phong_light(verts, normals))
+    t_nlight = gpu_time(lambda: mesh.phong_light(verts, None))
     t_rast = gpu_time(lambda: mesh.rasterize(verts, light, img))
     t_pncc = gpu_time(lambda: mesh_pncc.rasterize(verts, ncc, img))
 
     def pipeline():
         hm.flame.decode(p, proj=True, to_2d=False, flip_z=True, out=dec)
-        mesh.get_normal(dec["proj"], out=normals)
-        lt = mesh.phong_light(dec["proj"], normals)
+        lt = mesh.phong_light(dec["proj"], None)  # normals + light in one launch
         mesh.rasterize(dec["proj"], lt, img)
 
     t_pipe = gpu_time(pipeline, iters=100)
@@ -82,6 +82,7 @@ def main():
     out["config5_share_b64"] = {
         "get_normal": {"images_per_s": B / t_norm, "us_per_batch": t_norm * 1e6, "GBps_algorithmic": B * 120552 / t_norm / 1e9},
         "phong_light": {"images_per_s": B / t_light, "us_per_batch": t_light * 1e6},
+        "normals+phong_one_launch": {"images_per_s": B / t_nlight, "us_per_batch": t_nlight * 1e6},
         "rasterize_9976": {"images_per_s": B / t_rast, "us_per_batch": t_rast * 1e6, "GBps_algorithmic": B * 513768 / t_rast / 1e9,
                            "bbox_pixel_tests_image0": tests, "Gtests_per_s": tests * B / t_rast / 1e9},
         "pncc_6270": {"images_per_s": B / t_pncc, "us_per_batch": t_pncc * 1e6},
