@@ -160,3 +160,55 @@ def test_unsupported_alpha_and_empty_inputs():
     assert torch.all(empty.get_normal(torch.ones((2, 4, 3), device="cuda")) == 0)
     with pytest.raises(_lib.Dad3dError):
         Mesh(np.array([[0, 1, 7]], np.int32), 3, device=0)
+
+
+@pytest.mark.parametrize("case", ["dense_tile", "huge_triangles", "large_odd_image", "large_packed_image"])
+def test_raster_work_queue_paths_bit_exact(port_oracle, case):
+    """The paths a head mesh at 256x256 does not reach: tile lists longer than one sorting round (> 4096 entries),
+    tiles split 2x2 and 4x4 by the cost model, boxes as large as a tile (the 512-lane class), hundreds of tiles,
+    parts beyond the image edge, and the bytewise colour path (width not a multiple of 4)."""
+    rng = np.random.default_rng({"dense_tile": 1, "huge_triangles": 2, "large_odd_image": 3, "large_packed_image": 4}[case])
+    if case == "dense_tile":
+        h, w, c, nver, ntri = 256, 256, 3, 9000, 20000
+        v = np.empty((nver, 3), np.float32)
+        v[:, :2] = rng.uniform(70, 170, (nver, 2))
+        v[:, 2] = rng.uniform(-5, 5, nver)
+        base = rng.integers(0, nver, ntri)
+        # small triangles: the three corners are close neighbours in a sorted order of the vertices
+        order = np.lexsort((v[:, 1] // 4, v[:, 0] // 4))
+        pos = np.empty(nver, np.int64)
+        pos[order] = np.arange(nver)
+        t = np.stack([base, order[np.minimum(pos[base] + 1, nver - 1)], order[np.minimum(pos[base] + 2, nver - 1)]], 1).astype(np.int32)
+    elif case == "huge_triangles":
+        h, w, c, nver, ntri = 384, 512, 4, 40, 60
+        v = rng.uniform(-300, 800, (nver, 3)).astype(np.float32)
+        v[:, 2] = np.round(v[:, 2] / 200)  # depth ties between whole-image triangles
+        t = rng.integers(0, nver, (ntri, 3)).astype(np.int32)
+    else:
+        h, w, c = (777, 1030, 3) if case == "large_odd_image" else (700, 1032, 3)
+        nver, ntri = 3000, 6000
+        v = rng.uniform(-50, 1100, (nver, 3)).astype(np.float32)
+        near = rng.integers(0, nver, ntri)
+        t = np.stack([near, (near + rng.integers(1, 40, ntri)) % nver, (near + rng.integers(1, 40, ntri)) % nver], 1).astype(np.int32)
+        v[:, :2] = np.sort(v[:, :2], axis=0)  # neighbours in index are neighbours on screen: mid-sized triangles
+    col = rng.uniform(0, 1, (nver, c)).astype(np.float32)
+    bg = rng.integers(0, 255, (h, w, c)).astype(np.uint8)
+    mesh = Mesh(t, nver, device=0)
+    dv = torch.from_numpy(v).cuda()[None]
+    img = torch.from_numpy(bg.copy()).cuda()[None].contiguous()
+    depth = torch.full((1, h, w), -1e8, device="cuda")
+    mesh.rasterize(dv, torch.from_numpy(col).cuda()[None], img, depth=depth)
+    ref_img, ref_depth = port_oracle.rasterize(v, t, col, bg=bg.copy(), return_depth=True)
+    assert np.array_equal(img[0].cpu().numpy(), ref_img)
+    assert np.array_equal(depth[0].cpu().numpy(), ref_depth)
+    assert (ref_img != bg).any()
+    d, tb, bw = mesh.rasterize_triangles(dv, h, w)
+    rd, rtb, rbw = port_oracle.rasterize_triangles(v, t, h, w)
+    won = rtb >= 0
+    assert np.array_equal(d[0].cpu().numpy(), rd) and np.array_equal(tb[0].cpu().numpy()[won], rtb[won])
+    assert np.array_equal(bw[0].cpu().numpy()[won], rbw[won])
+    # a second batch shape on the same handle re-plans the scratch; the first result must be reproducible afterwards
+    two = torch.cat([dv, dv]).contiguous()
+    img2 = torch.from_numpy(np.stack([bg, bg])).cuda().contiguous()
+    mesh.rasterize(two, torch.from_numpy(np.stack([col, col])).cuda(), img2)
+    assert np.array_equal(img2[0].cpu().numpy(), ref_img) and np.array_equal(img2[1].cpu().numpy(), ref_img)
