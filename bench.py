@@ -92,6 +92,16 @@ def pmc_traffic_bytes():
         return None
 
 
+def pmc_mfma_busy():
+    """Fraction of the kernel's duration the MFMA pipes were busy, all SIMDs (SQ_VALU_MFMA_BUSY_CYCLES from the committed
+    rocprofv3 pass, profiles/r01_pmc_sq.json); null when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")) as f:
+            return json.load(f)["mfma_busy_fraction_of_kernel_time_all_1024_simds"]
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +216,7 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": flops / kern_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": pmc_traffic_bytes(),
+                "mfma_busy_pmc": pmc_mfma_busy(),
                 "kernel_us": kern_s * 1e6,
                 "algorithmic_flop_per_launch": flops,
                 "algorithmic_bytes_per_launch": alg_bytes,
