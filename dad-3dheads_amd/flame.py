@@ -171,7 +171,9 @@ class FLAMELayer(torch.nn.Module):
         self.landmark_indices = np.zeros((0,), dtype=np.int64)
 
     def __del__(self):
-        h, self._handle = getattr(self, "_handle", None), None
+        # plain dict access: nn.Module.__setattr__ is not safe to call while the interpreter shuts down
+        h = self.__dict__.get("_handle")
+        self.__dict__["_handle"] = None
         if h:
             try:
                 self._lib.dad3d_flame_destroy(h)
