@@ -66,6 +66,7 @@ SIGNATURES = {
     "dad3d_device_count": (_I, []),
     "dad3d_flame_create": (_I, [C.POINTER(FlameModelC), C.POINTER(FlameConstsC), _F, _I, C.POINTER(_P)]),
     "dad3d_flame_destroy": (None, [_P]),
+    "dad3d_flame_fork": (_I, [_P, C.POINTER(_P)]),
     "dad3d_flame_num_params": (_I, [_P]),
     "dad3d_flame_num_verts": (_I, [_P]),
     "dad3d_flame_set_landmarks": (_I, [_P, _P, _I]),

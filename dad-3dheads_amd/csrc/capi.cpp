@@ -37,6 +37,17 @@ using namespace dad3d;
 // =================================================================================================
 // FLAME
 // =================================================================================================
+// Read-only model constants on the device, shared by a handle and its forks (dad3d_flame_fork)
+struct FlameConsts {
+    int device = 0;
+    float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
+    ~FlameConsts() {
+        DeviceGuard guard(device);
+        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8})
+            if (p) (void)hipFree(p);
+    }
+};
+
 struct dad3d_flame {
     int device = 0;
     int n_verts = 0, n_betas = 0;
@@ -47,7 +58,7 @@ struct dad3d_flame {
     int n_tiles = 0, n_tiles_pad8 = 0;
     int max_shape = 300;
     float image_size = 256.f;
-    float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
+    std::shared_ptr<FlameConsts> c;
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
     int n_lmk = 0;
     float* d_imgc = nullptr;
@@ -189,8 +200,10 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
     std::vector<int> head(V, -1);
 
     dad3d_status st;
-    if ((st = upload(&h->d_bpack, bpack)) || (st = upload(&h->d_jdirs, jdirs)) || (st = upload(&h->d_j0, j0)) ||
-        (st = upload(&h->d_w8, w8)) || (st = upload(&h->d_lmk_head, head)) ||
+    h->c = std::make_shared<FlameConsts>();
+    h->c->device = device;
+    if ((st = upload(&h->c->d_bpack, bpack)) || (st = upload(&h->c->d_jdirs, jdirs)) || (st = upload(&h->c->d_j0, j0)) ||
+        (st = upload(&h->c->d_w8, w8)) || (st = upload(&h->d_lmk_head, head)) ||
         (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = upload(&h->d_sync, std::vector<unsigned>(4, 0u))) ||
         (st = flame_reserve(h.get(), 1))) {
         dad3d_flame_destroy(h.release());
@@ -203,12 +216,41 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
 void dad3d_flame_destroy(dad3d_flame* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
-    for (void* p : {(void*)h->d_bpack, (void*)h->d_jdirs, (void*)h->d_j0, (void*)h->d_w8, (void*)h->d_lmk_head,
-                    (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc})
+    for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc})
         if (p) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     delete h;
+}
+
+dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
+    DAD3D_REQUIRE(parent && out, "dad3d_flame_fork: bad argument");
+    *out = nullptr;
+    DeviceGuard guard(parent->device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", parent->device);
+    std::unique_ptr<dad3d_flame> h(new dad3d_flame(*parent));  // layout, tiling, shared constants
+    h->d_lmk_head = h->d_lmk_next = nullptr;
+    h->d_imgc = nullptr;
+    h->d_sync = nullptr;
+    h->cap_nbb = 0;
+    h->arrive_total = 0;
+    h->profiling = false;
+    h->d_trace = nullptr;
+    h->ev_first = h->ev_last = nullptr;
+    h->prof_launches = 0;
+    dad3d_status st = DAD3D_OK;
+    const size_t nv = (size_t)parent->n_verts, nl = (size_t)std::max(parent->n_lmk, 0);
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_lmk_head), std::max<size_t>(nv, 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_lmk_next), std::max<size_t>(nl, 1) * sizeof(int)) != hipSuccess ||
+        hipMemcpy(h->d_lmk_head, parent->d_lmk_head, nv * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess ||
+        (nl && hipMemcpy(h->d_lmk_next, parent->d_lmk_next, nl * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess) ||
+        (st = upload(&h->d_sync, std::vector<unsigned>(4, 0u))) != DAD3D_OK) {
+        if (st == DAD3D_OK) set_error("dad3d_flame_fork: device allocation or copy failed");
+        dad3d_flame_destroy(h.release());
+        return st == DAD3D_OK ? DAD3D_E_HIP : st;
+    }
+    *out = h.release();
+    return DAD3D_OK;
 }
 
 int dad3d_flame_num_params(const dad3d_flame* h) { return h ? h->lay.n_params : -1; }
@@ -253,10 +295,10 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     }
     DecodeArgs da{};
     da.params = params;
-    da.bpack = h->d_bpack;
-    da.jdirs = h->d_jdirs;
-    da.j0 = h->d_j0;
-    da.weights8 = h->d_w8;
+    da.bpack = h->c->d_bpack;
+    da.jdirs = h->c->d_jdirs;
+    da.j0 = h->c->d_j0;
+    da.weights8 = h->c->d_w8;
     da.lmk_head = h->d_lmk_head;
     da.lmk_next = h->d_lmk_next;
     da.imgc = h->d_imgc;

@@ -184,6 +184,16 @@ class FLAMELayer(torch.nn.Module):
     def torch_device(self) -> torch.device:
         return torch.device("cuda", self.device_index)
 
+    def fork(self) -> "FLAMELayer":
+        """A second layer for ANOTHER stream: shares the model constants on the device (dad3d_flame_fork), owns its
+        hand-off buffers and landmark list. One handle serves one stream at a time."""
+        handle = C.c_void_p()
+        _lib.check(self._lib.dad3d_flame_fork(self._handle, C.byref(handle)))
+        twin = object.__new__(type(self))
+        twin.__dict__ = {k: (dict(v) if isinstance(v, dict) else v) for k, v in self.__dict__.items()}
+        twin.__dict__["_handle"] = handle
+        return twin
+
     def set_landmarks(self, indices: Sequence[int]) -> None:
         idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int64))
         _lib.check(self._lib.dad3d_flame_set_landmarks(self._handle, idx.ctypes.data, int(idx.size)))

@@ -66,6 +66,13 @@ class HeadMesh(nn.Module):
         fp.translation = fp.translation + Tensor([[paddings[2], paddings[0], 0]]).to(params_3dmm.device) * 2 / self._image_size
         return fp.to_3dmm_tensor()
 
+    def fork(self) -> "HeadMesh":
+        """A HeadMesh for another stream (see `FLAMELayer.fork`): same model in HBM, independent launches."""
+        twin = object.__new__(type(self))
+        twin.__dict__ = {k: (dict(v) if isinstance(v, dict) else v) for k, v in self.__dict__.items()}
+        twin.flame = self.flame.fork()
+        return twin
+
     # -- fused entry ------------------------------------------------------------------------------
     def set_landmarks(self, indices: Sequence[int]) -> None:
         self.flame.set_landmarks(indices)

@@ -74,6 +74,11 @@ typedef struct dad3d_flame dad3d_flame; /* opaque: packed basis + scratch reside
 dad3d_status dad3d_flame_create(const dad3d_flame_model* model, const dad3d_flame_consts* consts, float image_size,
                                 int device, dad3d_flame** out);
 void dad3d_flame_destroy(dad3d_flame* h);
+/* A second handle on the same device that SHARES the model constants of `parent` (26 MB, reference counted: either may
+ * be destroyed first) and owns its hand-off buffers and landmark list (copied from the parent's current one). A handle
+ * serves one stream at a time -- its pose-role -> decode-role hand-off block is per handle -- so a serving loop that
+ * keeps several batches in flight uses one fork per stream (bench.py does, with two). */
+dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out);
 
 /* Number of floats per params row (sum of the consts; 413 for dad_3dnet.yaml). */
 int dad3d_flame_num_params(const dad3d_flame* h);

@@ -224,3 +224,46 @@ def test_pose_handoff_under_back_to_back_launches(hm, flame_consts):
     n = C.c_uint(99)
     _lib.check(_lib.load().dad3d_flame_handoff_timeouts(hm.flame._handle, C.byref(n)))
     assert n.value == 0, "decode workgroups fell back to computing the pose constants themselves"
+
+
+def test_forked_handles_on_two_streams_match_oracle(flame_model, flame_consts, static):
+    """dad3d_flame_fork: two handles sharing the model constants, launches interleaved on two streams (what bench.py
+    does). Every launch must produce exactly what a single-stream launch produces, the parent may die first."""
+    from dad_3dheads_amd import landmarks
+    from dad_3dheads_amd.head_mesh import HeadMesh
+
+    idx = landmarks.canonical("445", static)
+    hm_a = HeadMesh(flame_model=flame_model, landmarks=idx, static=static, device=0)
+    hm_b = hm_a.fork()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    pa = torch.from_numpy(synthetic.synthetic_params(64, seed=31)).cuda()
+    pb = torch.from_numpy(synthetic.synthetic_params(40, seed=32)).cuda()
+    ref_a = hm_a.decode(pa.clone(), landmarks=False, landmarks_px=True)
+    ref_a = {k: v.clone() for k, v in ref_a.items()}
+    outs_a, outs_b = {}, {}
+    torch.cuda.synchronize()
+    for _ in range(30):  # interleaved, no synchronisation in between
+        with torch.cuda.stream(streams[0]):
+            hm_a.decode(pa, landmarks=False, landmarks_px=True, out=outs_a)
+        with torch.cuda.stream(streams[1]):
+            hm_b.decode(pb, landmarks=False, landmarks_px=True, out=outs_b)
+    torch.cuda.synchronize()
+    for k in ("verts3d", "proj", "lmk_px"):
+        assert torch.equal(outs_a[k], ref_a[k]), k
+    ref_b = flame_ref.vertices_3d(flame_consts, pb.cpu().clone())
+    assert (outs_b["verts3d"].cpu() - ref_b).abs().max() < TOL_V
+    assert torch.equal(outs_b["lmk_px"], outs_b["proj"][:, torch.from_numpy(idx).cuda(), :].to(torch.int32))
+    lib = _lib.load()
+    for h in (hm_a.flame._handle, hm_b.flame._handle):
+        n = C.c_uint()
+        _lib.check(lib.dad3d_flame_handoff_timeouts(h, C.byref(n)))
+        assert n.value == 0
+    del hm_a  # the fork keeps the shared constants alive
+    again = hm_b.decode(pb, landmarks=False, landmarks_px=True)
+    torch.cuda.synchronize()
+    assert (again["verts3d"].cpu() - ref_b).abs().max() < TOL_V
+    # a fork carries its own landmark list
+    hm_c = hm_b.fork()
+    hm_c.set_landmarks(idx[:10])
+    assert hm_c.decode(pb, landmarks=False, landmarks_px=True)["lmk_px"].shape == (40, 10, 2)
+    assert hm_b.decode(pb, landmarks=False, landmarks_px=True)["lmk_px"].shape == (40, 445, 2)
