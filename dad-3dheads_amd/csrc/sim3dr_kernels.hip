@@ -575,15 +575,15 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
         Slot cur, nxt;
         int s0 = next_step();
         fetch(s0, cur);
-        unsigned long long d_steps = 0, d_wait = 0, d_work = 0, d_trips = 0;  // diagnostics (a.trace only)
+        unsigned d_steps = 0, d_wait = 0, d_work = 0, d_trips = 0;  // diagnostics (a.trace only)
         while (s0 < sb[kClasses]) {
             s0 = next_step();
             fetch(s0, nxt);
-            unsigned long long c0 = 0, c1 = 0;
+            unsigned c0 = 0, c1 = 0;
             if (a.trace) {
-                c0 = wall_clock64();
+                c0 = (unsigned)wall_clock64();
                 __builtin_amdgcn_s_waitcnt(0);
-                c1 = wall_clock64();
+                c1 = (unsigned)wall_clock64();
                 d_wait += c1 - c0, ++d_steps;
             }
             if (cur.valid) {
@@ -607,12 +607,12 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
                     if (a.trace) ++d_trips;
                 }
             }
-            if (a.trace) d_work += wall_clock64() - c1;
+            if (a.trace) d_work += (unsigned)wall_clock64() - c1;
             cur = nxt;
         }
         if (a.trace) {
-            unsigned long long mx = d_trips;
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned long long)__shfl_xor((long long)mx, o));
+            unsigned mx = d_trips;
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
             if (lane == 0) {
                 unsigned long long* tr = a.trace + ((size_t)item * kRasterWaves + (tid >> 6)) * 16 + trace_base;
                 tr[0] = d_steps, tr[1] = d_wait, tr[2] = d_work, tr[3] = mx;
@@ -645,137 +645,127 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     __syncthreads();
     stamp(3);
 
-    // (C) resolve: every pixel is shaded once from its winning triangle. A thread owns four horizontally adjacent
-    // pixels; their records (one 64-byte line each), vertex indices and colours are requested together so the two
-    // dependent memory round trips are paid once per quad, and when the row pitch allows it the 4*c colour bytes are
-    // merged into the background as whole dwords (byte stores are read-modify-writes in L2). The cost is the same
-    // for an item with 100 triangles and one with 4000.
+    // (C) resolve: every pixel is shaded once from the record of its winning triangle. A lane owns one pixel, the
+    // lanes of a wave a run of one row: neighbours mostly share the triangle, so their record / index / colour loads
+    // fall on the same addresses and coalesce in the texture unit, and depth, triangle ids and barycentrics leave as
+    // contiguous stores. Two pixels per lane are in flight so the two dependent round trips (record + indices, then
+    // colours) overlap. On the packed path (3 or 4 channels, row pitch a multiple of 4 pixels) the colour goes into
+    // the dead depth half of the key and (D) merges four pixels at a time into the image as whole dwords (byte stores
+    // are read-modify-writes in L2). The cost is the same for an item with 100 triangles and one with 4000.
     // C = compile-time channel count of the packed path (3: RGB, 4: RGBA), 0 = any count, bytewise.
     const float* cb_ = (MODE == 0) ? a.colors + b * a.m.nver * a.c : nullptr;
     auto resolve = [&](auto cc) {
         constexpr int C = decltype(cc)::value;
         constexpr bool packed = MODE == 0 && C != 0;
         constexpr int CC = C ? C : 1;
-        constexpr int NB = 4;
+        constexpr int NP = 2;  // pixels per lane in flight
         const int nc = C ? C : a.c;
-        const int qrow = edge / NB;  // quads per row of the item
-        for (int q = tid; q < qrow * th; q += kRasterThreads) {
-            const int ly = q / qrow, lx0 = (q - ly * qrow) * NB;
-            if (lx0 >= tw) continue;
-            const uint4 k01 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0)]);
-            const uint4 k23 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0) + 4]);
-            const unsigned lo[NB] = {k01.x, k01.z, k23.x, k23.z};
-            bool hit[NB];
-            unsigned f[NB];
+        const int npix = edge * th;
+        for (int p0 = tid; p0 < npix; p0 += NP * kRasterThreads) {
+            int lx[NP], ly[NP];
+            unsigned f[NP];
+            bool hit[NP];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                hit[k] = lx0 + k < tw && lo[k] != kNoTri;  // kNoTri: nothing beat the incoming depth
-                f[k] = hit[k] ? 0xFFFFFFFEu - lo[k] : 0u;
+            for (int k = 0; k < NP; ++k) {
+                const int p = p0 + k * kRasterThreads;
+                ly[k] = p / edge, lx[k] = p - ly[k] * edge;
+                const unsigned lo = (p < npix && lx[k] < tw) ? kw[2 * (ly[k] * kTile + lx[k])] : kNoTri;
+                hit[k] = lo != kNoTri;  // kNoTri: nothing beat the incoming depth, the pixel stays untouched
+                f[k] = hit[k] ? 0xFFFFFFFEu - lo : 0u;
             }
-            if (!(hit[0] || hit[1] || hit[2] || hit[3])) continue;
-            float4 r0[NB], r1[NB], r2[NB];
-            float z2[NB];
-            int i0[NB], i1[NB], i2[NB];
-            // a pixel with the same triangle as its left neighbour copies instead of loading (large triangles: most)
-            bool same[NB];
-            same[0] = false;
+            if (!(hit[0] || hit[1])) continue;
+            float4 r0[NP], r1[NP], r2[NP];
+            float z2[NP];
+            int i0[NP], i1[NP], i2[NP];
 #pragma unroll
-            for (int k = 1; k < NB; ++k) same[k] = f[k] == f[k - 1];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (!same[k]) {
-                    const float4* rp = rec_b + (size_t)f[k] * kRecF4;
-                    r0[k] = rp[0], r1[k] = rp[1], r2[k] = rp[2], z2[k] = rp[3].x;
-                    if (MODE == 0) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
-                }
+            for (int k = 0; k < NP; ++k) {
+                const float4* rp = rec_b + (size_t)f[k] * kRecF4;
+                r0[k] = rp[0], r1[k] = rp[1], r2[k] = rp[2], z2[k] = rp[3].x;
+                if (MODE == 0) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
             }
+            float u[NP], v[NP], w0[NP], z[NP];
 #pragma unroll
-            for (int k = 1; k < NB; ++k) {
-                if (same[k]) {
-                    r0[k] = r0[k - 1], r1[k] = r1[k - 1], r2[k] = r2[k - 1], z2[k] = z2[k - 1];
-                    if (MODE == 0) i0[k] = i0[k - 1], i1[k] = i1[k - 1], i2[k] = i2[k - 1];
-                }
-            }
-            const int gy = ty0 + ly;
-            const int row = (MODE == 0 && a.reverse) ? (a.h - 1 - gy) : gy;
-            float u[NB], v[NB], w0[NB], z[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
+            for (int k = 0; k < NP; ++k) {
                 TriSetup ts;
                 ts.x0 = r0[k].x, ts.y0 = r0[k].y, ts.ax = r0[k].z, ts.ay = r0[k].w, ts.bx = r1[k].x, ts.by = r1[k].y;
                 ts.d00 = r1[k].z, ts.d01 = r1[k].w, ts.d11 = r2[k].x, ts.inv = r2[k].y;
-                tri_uv(ts, (float)(tx0 + lx0 + k), (float)gy, u[k], v[k]);
+                tri_uv(ts, (float)(tx0 + lx[k]), (float)(ty0 + ly[k]), u[k], v[k]);
                 w0[k] = 1.0f - u[k] - v[k];
                 z[k] = w0[k] * r2[k].z + v[k] * r2[k].w + u[k] * z2[k];
             }
-            // the records are dead from here on: only now ask for the colours, or 4 x (13 + 3 + 9) registers are live
+            // the records are dead from here on: only now ask for the colours
             __builtin_amdgcn_sched_barrier(0);
-            float col[NB][3 * CC];
+            float col[NP][3 * CC];
             if (packed) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    if (same[k]) continue;
+                for (int k = 0; k < NP; ++k)
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch)
                         col[k][ch] = cb_[C * i0[k] + ch], col[k][C + ch] = cb_[C * i1[k] + ch], col[k][2 * C + ch] = cb_[C * i2[k] + ch];
-                }
-#pragma unroll
-                for (int k = 1; k < NB; ++k) {
-                    if (!same[k]) continue;
-#pragma unroll
-                    for (int ch = 0; ch < 3 * C; ++ch) col[k][ch] = col[k - 1][ch];
-                }
             }
-            const size_t pix0 = (size_t)gy * a.w + tx0 + lx0;
-            if (depth_b) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k)
-                    if (hit[k]) depth_b[pix0 + k] = z[k];
-            }
-            if (MODE == 1) {
-#pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    if (!hit[k]) continue;
-                    a.tri_buf[b * a.h * a.w + pix0 + k] = (int)f[k];
-                    float* bw = a.bary + (b * a.h * a.w + pix0 + k) * 3;
+            for (int k = 0; k < NP; ++k) {
+                if (!hit[k]) continue;
+                const int gx = tx0 + lx[k], gy = ty0 + ly[k];
+                const size_t pix = (size_t)gy * a.w + gx;
+                if (depth_b) depth_b[pix] = z[k];
+                if (MODE == 1) {
+                    a.tri_buf[b * a.h * a.w + pix] = (int)f[k];
+                    float* bw = a.bary + (b * a.h * a.w + pix) * 3;
                     bw[0] = w0[k];
                     bw[1] = v[k];
                     bw[2] = u[k];
-                }
-            } else if (packed) {
-                // (unsigned char)((1 - alpha) * old + alpha * 255 * col) with alpha == 1: the old value only
-                // contributes +0.0f, so the background is read only where the quad is partly covered
-                unsigned* quad = reinterpret_cast<unsigned*>(a.image + ((b * a.h + row) * a.w + tx0 + lx0) * CC);
-                unsigned char bytes[4 * CC];
-                if (!(hit[0] && hit[1] && hit[2] && hit[3])) {
-#pragma unroll
-                    for (int d = 0; d < CC; ++d) {
-                        const unsigned wv = quad[d];
-                        bytes[4 * d] = wv & 0xff, bytes[4 * d + 1] = (wv >> 8) & 0xff, bytes[4 * d + 2] = (wv >> 16) & 0xff, bytes[4 * d + 3] = wv >> 24;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    if (!hit[k]) continue;
+                } else if (packed) {
+                    // (unsigned char)((1 - alpha) * old + alpha * 255 * col) with alpha == 1: the old value only
+                    // contributes +0.0f
+                    unsigned pk = 0;
 #pragma unroll
                     for (int ch = 0; ch < CC; ++ch) {
                         const float cv = w0[k] * col[k][ch] + v[k] * col[k][CC + ch] + u[k] * col[k][2 * CC + ch];
-                        bytes[k * CC + ch] = (unsigned char)(f2i_x86(0.0f + 255.0f * cv) & 0xff);
+                        pk |= (unsigned)(f2i_x86(0.0f + 255.0f * cv) & 0xff) << (8 * ch);
                     }
-                }
-#pragma unroll
-                for (int d = 0; d < CC; ++d)
-                    quad[d] = (unsigned)bytes[4 * d] | ((unsigned)bytes[4 * d + 1] << 8) | ((unsigned)bytes[4 * d + 2] << 16) | ((unsigned)bytes[4 * d + 3] << 24);
-            } else {
-                for (int k = 0; k < NB; ++k) {
-                    if (!hit[k]) continue;
-                    uint8_t* px = a.image + ((b * a.h + row) * a.w + tx0 + lx0 + k) * nc;
+                    kw[2 * (ly[k] * kTile + lx[k]) + 1] = pk;  // the depth half of the key is dead by now
+                } else {
+                    const int row = a.reverse ? (a.h - 1 - gy) : gy;
+                    uint8_t* px = a.image + ((b * a.h + row) * a.w + gx) * nc;
                     for (int ch = 0; ch < nc; ++ch) {
                         const float cv = w0[k] * cb_[nc * i0[k] + ch] + v[k] * cb_[nc * i1[k] + ch] + u[k] * cb_[nc * i2[k] + ch];
                         px[ch] = (uint8_t)(f2i_x86(0.0f + 255.0f * cv) & 0xff);
                     }
                 }
             }
+        }
+        if (!packed) return;
+        __syncthreads();
+        // (D) four horizontally adjacent pixels = C whole dwords of the image row; the background is only read where
+        // the quad is partly covered
+        const int qrow = edge / 4;
+        for (int q = tid; q < qrow * th; q += kRasterThreads) {
+            const int ly = q / qrow, lx0 = (q - ly * qrow) * 4;
+            if (lx0 >= tw) continue;
+            const uint4 k01 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0)]);
+            const uint4 k23 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0) + 4]);
+            const unsigned lo[4] = {k01.x, k01.z, k23.x, k23.z}, hi[4] = {k01.y, k01.w, k23.y, k23.w};
+            const bool hit[4] = {lo[0] != kNoTri, lo[1] != kNoTri, lo[2] != kNoTri, lo[3] != kNoTri};
+            if (!(hit[0] || hit[1] || hit[2] || hit[3])) continue;
+            const int gy = ty0 + ly, row = a.reverse ? (a.h - 1 - gy) : gy;
+            unsigned* quad = reinterpret_cast<unsigned*>(a.image + ((b * a.h + row) * a.w + tx0 + lx0) * CC);
+            unsigned char bytes[4 * CC];
+            if (!(hit[0] && hit[1] && hit[2] && hit[3])) {
+#pragma unroll
+                for (int d = 0; d < CC; ++d) {
+                    const unsigned wv = quad[d];
+                    bytes[4 * d] = wv & 0xff, bytes[4 * d + 1] = (wv >> 8) & 0xff, bytes[4 * d + 2] = (wv >> 16) & 0xff, bytes[4 * d + 3] = wv >> 24;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (hit[k])
+#pragma unroll
+                    for (int ch = 0; ch < CC; ++ch) bytes[k * CC + ch] = (hi[k] >> (8 * ch)) & 0xff;
+#pragma unroll
+            for (int d = 0; d < CC; ++d)
+                quad[d] = (unsigned)bytes[4 * d] | ((unsigned)bytes[4 * d + 1] << 8) | ((unsigned)bytes[4 * d + 2] << 16) | ((unsigned)bytes[4 * d + 3] << 24);
         }
     };
     {
