@@ -58,6 +58,16 @@ __device__ __forceinline__ TriSetup tri_setup(float x0, float y0, float x1, floa
     return t;
 }
 
+// TriSetup from a record (the dot products are not stored: same expressions as tri_setup, so the same bits)
+__device__ __forceinline__ TriSetup setup_from_record(const float4& r0, const float4& r1) {
+    TriSetup t;
+    t.x0 = r0.x, t.y0 = r0.y, t.ax = r0.z, t.ay = r0.w, t.bx = r1.x, t.by = r1.y, t.inv = r1.z;
+    t.d00 = t.ax * t.ax + t.ay * t.ay;
+    t.d01 = t.ax * t.bx + t.ay * t.by;
+    t.d11 = t.bx * t.bx + t.by * t.by;
+    return t;
+}
+
 __device__ __forceinline__ void tri_uv(const TriSetup& t, float px, float py, float& u, float& v) {
     const float cx = px - t.x0, cy = py - t.y0;  // v2 = p - p0
     const float d02 = t.ax * cx + t.ay * cy;
@@ -207,16 +217,16 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m
 // ------------------------------------------------------------------------------------------------
 // rasterisation
 // ------------------------------------------------------------------------------------------------
-// Three launches per batch:
+// Two launches per batch:
 //   tri_geometry_kernel  one lane per triangle, once per image. The vertices of the image are staged in LDS
 //                        (60 KB for FLAME), so the corner coordinates are LDS gathers instead of scattered global
 //                        loads. It writes one 64-byte record per triangle -- the screen bounding box exactly as
 //                        rasterize_kernel.cpp:246-254 computes it, the pixel-independent half of get_point_weight
 //                        (TriSetup) and the corner depths -- and appends the triangle to the list of every 64x64
 //                        screen tile its box touches (LDS counters, one global atomic per block and tile).
-//   raster_queue_kernel  one block: turns the tile counters into a work queue, heaviest first; a tile with more
-//                        than kSplit1 (kSplit2) triangles becomes 4 (16) items of 32x32 (16x16) pixels, so no item
-//                        is much heavier than the rest (eyes, lips and ears of a head mesh put 3000+ triangles
+//                        Its last block to finish turns the tile counters into a work queue, heaviest first; a tile
+//                        that costs more than kSplit1 (kSplit2) becomes 4 (16) items of 32x32 (16x16) pixels, so no
+//                        item is much heavier than the rest (eyes, lips and ears of a head mesh put 3000+ triangles
 //                        into one tile while most tiles hold a few hundred).
 //   raster_kernel        persistent workgroups pull items. Per item, keys in LDS: (A) counting-sort the tile list by
 //                        box area into 12 classes; a class-c triangle gets 2^max(c-2,0) lanes, so every lane of a
@@ -233,8 +243,10 @@ constexpr int kListCap = 4096;       // list entries sorted per round (u32 ids, 
 constexpr int kListPerThread = kListCap / kRasterThreads;
 constexpr int kClasses = 12;         // box area <=2, <=4, <=8, <=16, ... <=4096 (= a whole tile)
 constexpr int kSpread = 16;          // copies of every class counter: 64 lanes hit 16 addresses instead of one
-constexpr int kRecF4 = 4;            // one 64-byte record per (image, triangle): x0 y0 ax ay | bx by d00 d01 |
-                                     // d11 inv z0 z1 | z2 box.x box.y 0  -- exactly one cache line, read as 4 x b128
+constexpr int kRecF4 = 3;            // one 48-byte record per (image, triangle): x0 y0 ax ay | bx by inv z0 |
+                                     // z1 z2 box.x box.y -- read as 3 x b128. The dot products d00 d01 d11 of TriSetup are
+                                     // recomputed by the reader (9 ALU ops, the same expressions: identical bits): the
+                                     // record stream is the largest cost of the geometry kernel and of the resolve
 constexpr int kGeoThreads = kStageThreads;
 constexpr int kGeoPerThread = 3;
 constexpr int kGeoTrisPerBlock = kGeoThreads * kGeoPerThread;
@@ -264,10 +276,54 @@ struct RasterScratch {
     unsigned* counts;   // [2][B * ntiles]  triangles in a tile list, then the sum of their box areas inside the tile;
                         //                  zero between launches (the queue kernel resets them)
     unsigned* lists;    // [B * ntiles][ntri]   triangle | area class within the tile << 28
-    unsigned* qhdr;     // [0] work items in the queue  [1] next item to hand out
+    unsigned* qhdr;     // [0] work items in the queue  [1] next item to hand out  [2] geometry blocks finished
     uint2* queue;       // [16 * B * ntiles]  .x = tile index | split level << 24 | part << 26, .y = list length
     int tiles_x, tiles_y;
 };
+
+// Work queue, heaviest items first (bucket sort on cost / parts); resets the tile counters. Run by ONE block of
+// kGeoThreads threads -- the last block of tri_geometry_kernel to finish -- with `hist` = kQueueBuckets words of LDS.
+// The counters were written by other blocks' agent-scope atomics: they are read with agent-scope atomic loads.
+__device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned* hist, int tid) {
+    if (tid < kQueueBuckets) hist[tid] = 0;
+    __syncthreads();
+    auto count_of = [&](int i) { return __hip_atomic_load(&sc.counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // cost of a tile ~ pixel tests (box areas) + a per-triangle overhead; a part costs about a quarter / sixteenth
+    auto plan = [&](unsigned c, unsigned area, int& level, int& bucket) {
+        const unsigned cost = area + 8 * c;
+        level = cost > kSplit2 ? 2 : cost > kSplit1 ? 1 : 0;
+        bucket = min((int)((cost >> (2 * level)) >> 10), kQueueBuckets - 1);
+    };
+    for (int i = tid; i < n_lists; i += kGeoThreads) {
+        const unsigned c = count_of(i);
+        if (!c) continue;
+        int level, bucket;
+        plan(c, count_of(n_lists + i), level, bucket);
+        atomicAdd(&hist[bucket], 1u << (2 * level));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int k = kQueueBuckets - 1; k >= 0; --k) {
+            const unsigned n = hist[k];
+            hist[k] = run;  // becomes the write cursor of the bucket
+            run += n;
+        }
+        sc.qhdr[0] = run;
+        sc.qhdr[1] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_lists; i += kGeoThreads) {
+        const unsigned c = count_of(i);
+        if (!c) continue;
+        int level, bucket;
+        plan(c, count_of(n_lists + i), level, bucket);
+        sc.counts[i] = 0, sc.counts[n_lists + i] = 0;  // leave the list empty for the next launch
+        const unsigned parts = 1u << (2 * level);
+        const unsigned pos = atomicAdd(&hist[bucket], parts);
+        for (unsigned p = 0; p < parts; ++p) sc.queue[pos + p] = make_uint2((unsigned)i | ((unsigned)level << 24) | (p << 26), c);
+    }
+}
 
 #ifndef DAD3D_K1_ABLATE  // diagnostics only (tools/k1_ablate.sh): 1 no LDS binning atomics, 2 no list writes, 4 no records
 #define DAD3D_K1_ABLATE 0
@@ -311,9 +367,8 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
         // the frame) is in none and needs none -- the record stream is the largest cost of this kernel
         if ((bx0 <= bx1 && !(DAD3D_K1_ABLATE & 4)) || ts.inv == 12345.0f) {
             rp[0] = make_float4(ts.x0, ts.y0, ts.ax, ts.ay);
-            rp[1] = make_float4(ts.bx, ts.by, ts.d00, ts.d01);
-            rp[2] = make_float4(ts.d11, ts.inv, z0, z1);
-            rp[3] = make_float4(z2, __uint_as_float(box[k].x), __uint_as_float(box[k].y), 0.0f);
+            rp[1] = make_float4(ts.bx, ts.by, ts.inv, z0);
+            rp[2] = make_float4(z1, z2, __uint_as_float(box[k].x), __uint_as_float(box[k].y));
         }
         if (bx0 <= bx1 && !(DAD3D_K1_ABLATE & 1))
             for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
@@ -349,49 +404,19 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
                 sc.lists[(b * ntiles + t) * nt + atomicAdd(&cnt[t], 1u)] = (unsigned)f | ((unsigned)area_class(cw * ch) << 28);
             }
     }
-}
-
-// Work queue, heaviest items first (bucket sort on list length / parts); resets the tile counters.
-__global__ __launch_bounds__(1024) void raster_queue_kernel(RasterScratch sc, int n_lists) {
-    __shared__ unsigned hist[kQueueBuckets];
-    const int tid = threadIdx.x;
-    if (tid < kQueueBuckets) hist[tid] = 0;
+    // The last block to get here turns the counters into the work queue (one launch and its gap less than a kernel of
+    // its own). Ordering without a fence (an agent-scope release fence writes back the L2, i.e. the whole record
+    // stream: measured 195 us): the counter updates are agent-scope atomics, performed at the coherence point; every
+    // thread drains its own (vmcnt) before the barrier, the ticket is taken after it, and the last block reads the
+    // counters with agent-scope atomic loads.
+    __shared__ unsigned s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // cost of a tile ~ pixel tests (box areas) + a per-triangle overhead; a part costs about a quarter / sixteenth
-    auto plan = [&](unsigned c, unsigned area, int& level, int& bucket) {
-        const unsigned cost = area + 8 * c;
-        level = cost > kSplit2 ? 2 : cost > kSplit1 ? 1 : 0;
-        bucket = min((int)((cost >> (2 * level)) >> 10), kQueueBuckets - 1);
-    };
-    for (int i = tid; i < n_lists; i += 1024) {
-        const unsigned c = sc.counts[i];
-        if (!c) continue;
-        int level, bucket;
-        plan(c, sc.counts[n_lists + i], level, bucket);
-        atomicAdd(&hist[bucket], 1u << (2 * level));
-    }
+    if (tid == 0) s_ticket = atomicAdd(&sc.qhdr[2], 1u);
     __syncthreads();
-    if (tid == 0) {
-        unsigned run = 0;
-        for (int k = kQueueBuckets - 1; k >= 0; --k) {
-            const unsigned n = hist[k];
-            hist[k] = run;  // becomes the write cursor of the bucket
-            run += n;
-        }
-        sc.qhdr[0] = run;
-        sc.qhdr[1] = 0;
-    }
-    __syncthreads();
-    for (int i = tid; i < n_lists; i += 1024) {
-        const unsigned c = sc.counts[i];
-        if (!c) continue;
-        int level, bucket;
-        plan(c, sc.counts[n_lists + i], level, bucket);
-        sc.counts[i] = 0, sc.counts[n_lists + i] = 0;  // leave the list empty for the next launch
-        const unsigned parts = 1u << (2 * level);
-        const unsigned pos = atomicAdd(&hist[bucket], parts);
-        for (unsigned p = 0; p < parts; ++p) sc.queue[pos + p] = make_uint2((unsigned)i | ((unsigned)level << 24) | (p << 26), c);
-    }
+    if (s_ticket != gridDim.x * gridDim.y - 1) return;
+    build_work_queue(sc, (int)gridDim.y * ntiles, cnt, tid);  // cnt[]: this block's LDS counters are dead by now
+    if (tid == 0) sc.qhdr[2] = 0;
 }
 
 struct RasterArgs {
@@ -471,8 +496,8 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
 
     stamp(12);
     // (A) list entries [r * kListCap, ...) -> slist sorted by class of the box area inside the item
-    auto clipped_area = [&](float4 r3) {
-        const unsigned bx = __float_as_uint(r3.y), by = __float_as_uint(r3.z);
+    auto clipped_area = [&](float4 r2) {
+        const unsigned bx = __float_as_uint(r2.z), by = __float_as_uint(r2.w);
         const int x0 = max((int)(bx & 0xffff), tx0), x1 = min((int)(bx >> 16), tx1);
         const int y0 = max((int)(by & 0xffff), ty0), y1 = min((int)(by >> 16), ty1);
         return (x1 < x0 || y1 < y0) ? 0 : (x1 - x0 + 1) * (y1 - y0 + 1);
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
                 fv[k] = e & kIdMask;
                 cl[k] = (int)(e >> 28);
                 if (level > 0) {  // a part of the tile: drop the triangles that miss it, re-class the others
-                    const int area = clipped_area(rec_b[(size_t)fv[k] * kRecF4 + 3]);
+                    const int area = clipped_area(rec_b[(size_t)fv[k] * kRecF4 + 2]);
                     cl[k] = area > 0 ? area_class(area) : -1;
                 }
                 if (cl[k] >= 0) atomicAdd(&ccount[cl[k]][copy], 1);
@@ -541,7 +566,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     // triangle stride over its row-major box).
     // The record of the next wave step is requested before the pixels of the current one are worked on.
     struct Slot {
-        float4 r0, r1, r2, r3;
+        float4 r0, r1, r2;
         int f, sub, lg;
         bool valid;
     };
@@ -562,7 +587,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             if (ti >= cnum[c]) return;
             sl.f = (int)slist[cbase[c] + ti];
             const float4* rp = rec_b + (size_t)sl.f * kRecF4;
-            sl.r0 = rp[0], sl.r1 = rp[1], sl.r2 = rp[2], sl.r3 = rp[3];
+            sl.r0 = rp[0], sl.r1 = rp[1], sl.r2 = rp[2];
             sl.valid = true;
         };
         // waves take steps from an LDS counter: a step costs 1 to 8 pixel tests per lane, mostly outside or mostly
@@ -589,10 +614,9 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             if (cur.valid) {
                 TriLane t;
                 t.f = cur.f;
-                t.ts.x0 = cur.r0.x, t.ts.y0 = cur.r0.y, t.ts.ax = cur.r0.z, t.ts.ay = cur.r0.w;
-                t.ts.bx = cur.r1.x, t.ts.by = cur.r1.y, t.ts.d00 = cur.r1.z, t.ts.d01 = cur.r1.w;
-                t.ts.d11 = cur.r2.x, t.ts.inv = cur.r2.y, t.z0 = cur.r2.z, t.z1 = cur.r2.w, t.z2 = cur.r3.x;
-                const unsigned bbx = __float_as_uint(cur.r3.y), bby = __float_as_uint(cur.r3.z);
+                t.ts = setup_from_record(cur.r0, cur.r1);
+                t.z0 = cur.r1.w, t.z1 = cur.r2.x, t.z2 = cur.r2.y;
+                const unsigned bbx = __float_as_uint(cur.r2.z), bby = __float_as_uint(cur.r2.w);
                 t.bx0 = max((int)(bbx & 0xffff), tx0);
                 t.by0 = max((int)(bby & 0xffff), ty0);
                 const int bw = min((int)(bbx >> 16), tx1) - t.bx0 + 1, bh = min((int)(bby >> 16), ty1) - t.by0 + 1;
@@ -674,24 +698,22 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
                 f[k] = hit[k] ? 0xFFFFFFFEu - lo : 0u;
             }
             if (!(hit[0] || hit[1])) continue;
-            float4 r0[NP], r1[NP], r2[NP];
-            float z2[NP];
+            float4 r0[NP], r1[NP];
+            float z1[NP], z2[NP];
             int i0[NP], i1[NP], i2[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const float4* rp = rec_b + (size_t)f[k] * kRecF4;
-                r0[k] = rp[0], r1[k] = rp[1], r2[k] = rp[2], z2[k] = rp[3].x;
+                r0[k] = rp[0], r1[k] = rp[1], z1[k] = rp[2].x, z2[k] = rp[2].y;
                 if (MODE == 0) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
             }
             float u[NP], v[NP], w0[NP], z[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                TriSetup ts;
-                ts.x0 = r0[k].x, ts.y0 = r0[k].y, ts.ax = r0[k].z, ts.ay = r0[k].w, ts.bx = r1[k].x, ts.by = r1[k].y;
-                ts.d00 = r1[k].z, ts.d01 = r1[k].w, ts.d11 = r2[k].x, ts.inv = r2[k].y;
+                const TriSetup ts = setup_from_record(r0[k], r1[k]);
                 tri_uv(ts, (float)(tx0 + lx[k]), (float)(ty0 + ly[k]), u[k], v[k]);
                 w0[k] = 1.0f - u[k] - v[k];
-                z[k] = w0[k] * r2[k].z + v[k] * r2[k].w + u[k] * z2[k];
+                z[k] = w0[k] * r1[k].w + v[k] * z1[k] + u[k] * z2[k];
             }
             // the records are dead from here on: only now ask for the colours
             __builtin_amdgcn_sched_barrier(0);
@@ -960,7 +982,7 @@ struct ScratchLayout {
         rec = 0;
         counts = align256(rec + batch * nt * kRecF4 * sizeof(float4));
         qhdr = align256(counts + 2 * nlists * sizeof(unsigned));
-        queue = align256(qhdr + 2 * sizeof(unsigned));
+        queue = align256(qhdr + 4 * sizeof(unsigned));
         lists = align256(queue + nlists * kMaxSubs * sizeof(uint2));
         total = align256(lists + nlists * nt * sizeof(unsigned));
     }
@@ -988,7 +1010,7 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
     DAD3D_REQUIRE((unsigned)m.ntri <= kIdMask, "rasterize: more than 2^28 triangles");
     DAD3D_REQUIRE(scratch, "rasterize: no scratch buffer");
     static int persistent_blocks[2] = {0, 0};
-    constexpr int kMaxLds = 160 * 1024;
+    constexpr int kMaxLds = 160 * 1024 - 256;  // dynamic part: the geometry kernel also has a few static words
     if (!persistent_blocks[0]) {
         DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
@@ -1008,7 +1030,7 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
     const int ntiles = sc.tiles_x * sc.tiles_y;
     {
         const dim3 ggrid((m.ntri + kGeoTrisPerBlock - 1) / kGeoTrisPerBlock, batch);
-        const size_t cnt_bytes = 2 * (size_t)ntiles * sizeof(unsigned);
+        const size_t cnt_bytes = std::max<size_t>(2 * (size_t)ntiles, kQueueBuckets) * sizeof(unsigned);  // counters, later the queue histogram
         const size_t vlds = ((size_t)m.nver * 3 + 12) * sizeof(float) + cnt_bytes;
         if (vlds <= (size_t)kMaxLds)
             hipLaunchKernelGGL(tri_geometry_kernel<true>, ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w);
@@ -1016,8 +1038,6 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
             hipLaunchKernelGGL(tri_geometry_kernel<false>, ggrid, dim3(kGeoThreads), 48 + cnt_bytes, s, m, vertices, sc, h, w);
         DAD3D_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(raster_queue_kernel, dim3(1), dim3(1024), 0, s, sc, (int)nlists);
-    DAD3D_HIP_TRY(hipGetLastError());
     RasterArgs a{m, sc, image, colors, depth, tri_buf, bary, trace, h, w, c, reverse};
     const int blocks = (int)std::min<size_t>(persistent_blocks[mode ? 1 : 0], nlists * kMaxSubs);
     if (mode == 0)

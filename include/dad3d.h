@@ -157,7 +157,7 @@ dad3d_status dad3d_mesh_get_ver_normal(dad3d_mesh* m, float* ver_normal, const f
  * Bit-exact with the reference for alpha == 1: strict-interior test, `>` depth test, ties to the
  * lowest triangle index, (unsigned char) truncation.
  * Scratch: the handle owns device memory for the per-image triangle records, the 64x64-tile lists and the work queue
- * (about (64 + 4 * tiles) * ntri bytes per image, allocated on first use and when (B, h, w) grows -- that call
+ * (about (48 + 4 * tiles) * ntri bytes per image, allocated on first use and when (B, h, w) grows -- that call
  * synchronises the device). One handle serves one stream at a time; use one handle per concurrent stream.
  * Limits: at most 4096 tiles of 64x64 pixels per image (4096 x 4096, 16384 x 1024, ...), B * tiles < 2^24,
  * ntri < 2^28; beyond them DAD3D_E_INVALID with a message. */

@@ -212,3 +212,26 @@ def test_raster_work_queue_paths_bit_exact(port_oracle, case):
     img2 = torch.from_numpy(np.stack([bg, bg])).cuda().contiguous()
     mesh.rasterize(two, torch.from_numpy(np.stack([col, col])).cuda(), img2)
     assert np.array_equal(img2[0].cpu().numpy(), ref_img) and np.array_equal(img2[1].cpu().numpy(), ref_img)
+
+
+def test_back_to_back_rasterisations_are_stable(static, decode_golden):
+    """The work queue of a launch is built by the last block of the geometry kernel from counters other blocks
+    updated (agent-scope atomics, no fence) and consumed by the next kernel; 60 launches queued without any host
+    synchronisation, alternating two batch shapes on one handle, must all give the same images."""
+    verts, faces = head_inputs(static, decode_golden)
+    mesh = Mesh(faces, 5023, device=0)
+    base = torch.from_numpy(verts).cuda()
+    scale = torch.linspace(0.6, 1.3, 16, device="cuda")[:, None, None]
+    v16 = (base[None] * scale).contiguous()
+    v5 = v16[3:8].contiguous()
+    col = torch.rand((16, 5023, 3), device="cuda")
+    first16 = mesh.rasterize(v16, col, torch.zeros((16, 256, 256, 3), dtype=torch.uint8, device="cuda")).clone()
+    first5 = mesh.rasterize(v5, col[3:8].contiguous(), torch.zeros((5, 200, 312, 3), dtype=torch.uint8, device="cuda")).clone()
+    assert first16.any() and first5.any()
+    outs = []
+    for i in range(30):
+        outs.append(mesh.rasterize(v16, col, torch.zeros((16, 256, 256, 3), dtype=torch.uint8, device="cuda")))
+        outs.append(mesh.rasterize(v5, col[3:8].contiguous(), torch.zeros((5, 200, 312, 3), dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, first16 if i % 2 == 0 else first5), i
