@@ -16,9 +16,11 @@
 //     the order the serial loop does. No atomics, deterministic.
 //   * raster: the serial "draw if deeper than the z-buffer" keeps, per pixel, the deepest fragment and
 //     on ties the lowest triangle index. That is a max over the 64-bit key
-//     (orderable(depth) << 32 | ~tri): one workgroup owns a 128x128 screen tile whose keys live in LDS
-//     (128 KiB), lanes stride over the triangle list and ds_max_u64 their fragments, then every pixel
-//     is resolved once from the winning triangle. The z-buffer never touches HBM.
+//     (orderable(depth) << 32 | ~tri): a workgroup owns a 64x64 screen tile (or a part of one) whose keys
+//     live in LDS, lanes ds_max_u64 the fragments of the triangles binned to the tile, then every pixel is
+//     resolved once from the winning triangle. The z-buffer never touches HBM. (Section "rasterisation".)
+//   * every gather kernel first stages the image's vertices in LDS: a scattered 4-byte global load costs a
+//     64-byte request per lane, an LDS gather a bank access.
 #include <algorithm>
 #include <climits>
 #include <type_traits>
