@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Build tests/golden/lmk68_embedding.npz: the 68-landmark barycentric embedding of the FLAME topology and golden
+outputs of the reference's OWN `get_68_landmarks` (dad_3dheads_benchmark/utils.py:99-117 == model_training/data/utils.py:
+188-204), executed unmodified from where it lies.
+
+Runs ONLY in the authoring container (needs /root/reference). Stand-ins for the two imports that are not installed:
+`cv2` (never called on this path) and `smplx` -- `Struct` (attribute bag) and `find_dynamic_lmk_idx_and_bcoords`,
+restated for the only way the reference calls it: a ZERO pose. With a zero pose every rotation of the neck chain is the
+identity, the yaw angle is 0 and the function returns row 0 of the contour tables (smplx 0.1.26, lbs.py: `y_rot_angle =
+round(clamp(-yaw * 180 / pi, max=39))`, negative angles remapped, then `index_select(table, 0, y_rot_angle)`); the stub
+asserts the pose really is zero. PARITY UNPINNED for that one function, like `smplx.lbs.lbs` (see oracle/flame_ref.py).
+
+  face_idx   int64 [68]     dynamic row 0 (17 contour points) then the 51 static points
+  b_coords   f32   [68,3]
+  verts      f32   [3,5023,3] seeded test meshes          lmk68  f32 [3,68,3] = reference get_68_landmarks(verts[i])
+The tables are (c) the FLAME / DAD-3DHeads authors (see NOTICE.md); data, not code.
+"""
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("DAD3D_REFERENCE_ROOT", "/root/reference")
+BENCH = os.path.join(REF, "dad_3dheads_benchmark")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lmk68_embedding.npz")
+
+
+def install_stubs():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    smplx = types.ModuleType("smplx")
+    lbs = types.ModuleType("smplx.lbs")
+    utils = types.ModuleType("smplx.utils")
+
+    class Struct:
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+    def find_dynamic_lmk_idx_and_bcoords(vertices, pose, dynamic_lmk_faces_idx, dynamic_lmk_b_coords, neck_kin_chain, dtype=torch.float32):
+        assert float(pose.abs().max()) == 0.0, "the stub covers the reference's only call: a zero pose"
+        y_rot_angle = torch.zeros(vertices.shape[0], dtype=torch.long)
+        return torch.index_select(dynamic_lmk_faces_idx, 0, y_rot_angle), torch.index_select(dynamic_lmk_b_coords, 0, y_rot_angle)
+
+    lbs.find_dynamic_lmk_idx_and_bcoords = find_dynamic_lmk_idx_and_bcoords
+    utils.Struct = Struct
+    smplx.lbs, smplx.utils = lbs, utils
+    sys.modules.update({"smplx": smplx, "smplx.lbs": lbs, "smplx.utils": utils})
+
+
+def main():
+    install_stubs()
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, BENCH)
+    os.chdir(BENCH)  # the reference opens "data/static/..." relative to its own directory
+    import utils as ref_utils  # dad_3dheads_benchmark/utils.py
+
+    dyn = np.load("data/static/flame_dynamic_embedding.npy", allow_pickle=True, encoding="latin1")[()]
+    with open("data/static/flame_static_embedding.pkl", "rb") as f:
+        sta = pickle.load(f, encoding="latin1")
+    face_idx = np.concatenate([np.array(dyn["lmk_face_idx"]).astype(np.int64)[0], sta["lmk_face_idx"].astype(np.int64)])
+    b_coords = np.concatenate([np.array(dyn["lmk_b_coords"])[0], sta["lmk_b_coords"]]).astype(np.float32)
+    assert face_idx.shape == (68,) and b_coords.shape == (68, 3)
+    g = torch.Generator().manual_seed(68)
+    verts = (torch.randn(3, 5023, 3, generator=g) * 0.1).float()
+    lmk = torch.stack([ref_utils.get_68_landmarks(v) for v in verts])
+    seven = np.stack([ref_utils.get_7_landmarks_from_68(l) for l in lmk])
+    np.savez_compressed(OUT, face_idx=face_idx, b_coords=b_coords, verts=verts.numpy(), lmk68=lmk.numpy(), lmk7=seven)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes; lmk68", lmk.shape, "lmk7", seven.shape)
+
+
+if __name__ == "__main__":
+    main()

@@ -149,3 +149,15 @@ def test_device_resident_batch_matches_reference_postprocess(net_predictor, flam
     assert (res["projected_vertices"].cpu() - proj).abs().max() < 2e-3
     idx = torch.from_numpy(np.asarray(net_predictor.head_mesh.flame.landmark_indices)).long()
     assert torch.equal(res["landmarks"].cpu(), res["projected_vertices"].cpu()[:, idx, :].to(torch.int32))
+
+
+def test_68_landmarks_on_device_equal_host(net_predictor, static):
+    from dad_3dheads_amd.benchmark_export import Landmarks68, seven_landmarks
+
+    params = torch.from_numpy(synthetic.synthetic_params(5, seed=44)).cuda()
+    verts = net_predictor.head_mesh.decode(params, proj=False, landmarks=False)["verts3d"]
+    lm = Landmarks68(static["faces"], device=verts.device)
+    on_dev = lm(verts)
+    assert on_dev.is_cuda and on_dev.shape == (5, 68, 3)
+    assert torch.equal(on_dev.cpu(), Landmarks68(static["faces"])(verts.cpu()))
+    assert seven_landmarks(on_dev).shape == (5, 7, 3)

@@ -160,3 +160,33 @@ def test_ncc_color_codes():
         compute_ncc_color_codes(t.tolist())
     with pytest.raises(ValueError):
         compute_ncc_color_codes(t[:, :2])
+
+
+def test_68_landmark_embedding_matches_reference_goldens(tmp_path):
+    """benchmark_export.Landmarks68 vs outputs of the reference's own get_68_landmarks / get_7_landmarks_from_68
+    (tests/golden/make_lmk68_fixture.py), and the submission wire format of the benchmark README."""
+    import json
+
+    import torch
+
+    from dad_3dheads_amd import benchmark_export as bx
+    from dad_3dheads_amd import synthetic
+
+    st = synthetic.load_static()
+    with np.load(bx.embedding_path()) as z:
+        verts, want68, want7 = torch.from_numpy(z["verts"]), z["lmk68"], z["lmk7"]
+    lm = bx.Landmarks68(st["faces"])
+    got = lm(verts)
+    assert got.shape == (3, 68, 3) and np.array_equal(got.numpy(), want68)  # same three products, same order: same bits
+    assert np.array_equal(lm(verts[1]).numpy(), want68[1])
+    assert np.array_equal(bx.seven_landmarks(got).numpy(), want7)
+    with pytest.raises(AssertionError):
+        lm(verts[:, :100])
+    rot = torch.eye(3)
+    entry = bx.submission_entry(torch.zeros(68, 2), verts[0][:10], got[0], rot)
+    assert list(entry) == ["68_landmarks_2d", "N_landmarks_3d", "7_landmarks_3d", "rotation_matrix"]
+    assert len(entry["68_landmarks_2d"]) == 68 and len(entry["7_landmarks_3d"]) == 7 and len(entry["rotation_matrix"]) == 3
+    p = tmp_path / "sub.json"
+    bx.write_submission(str(p), {"item_0": entry})
+    back = json.loads(p.read_text())
+    assert back["item_0"]["7_landmarks_3d"] == [[float(x) for x in row] for row in want7[0]]
