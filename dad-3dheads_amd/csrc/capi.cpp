@@ -558,6 +558,18 @@ dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices
                             static_cast<hipStream_t>(stream));
 }
 
+dad3d_status dad3d_project_vertices(const float* vertices, const float* model_view, const float* projection,
+                                    const float* frame, int batch, int nver, float* world_homo, float* xy,
+                                    int32_t* xy_int, int device, void* stream) {
+    DAD3D_REQUIRE(batch >= 0 && nver >= 0, "dad3d_project_vertices: bad argument");
+    if (batch == 0 || nver == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(vertices && model_view && projection && frame, "dad3d_project_vertices: null input");
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    return launch_project_vertices(vertices, model_view, projection, frame, batch, nver, world_homo, xy, xy_int,
+                                   static_cast<hipStream_t>(stream));
+}
+
 dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer) {
     DAD3D_REQUIRE(m, "null handle");
     m->d_trace = device_buffer;

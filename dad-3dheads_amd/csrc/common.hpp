@@ -129,4 +129,9 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
 dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals,
                           float* normals_out, int batch, const dad3d_light& cfg, hipStream_t s);
 
+// matrix projection (flame_dataset.py:115-141): frame = [B][3] (image height, crop x, crop y)
+dad3d_status launch_project_vertices(const float* vertices, const float* model_view, const float* projection,
+                                     const float* frame, int batch, int nver, float* world_homo, float* xy, int32_t* xy_int,
+                                     hipStream_t s);
+
 }  // namespace dad3d

@@ -190,6 +190,18 @@ dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* v
  * tiles = ceil(w/64) * ceil(h/64). */
 dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer);
 
+/* ---------------------------------------------------------------------------------------------
+ * Matrix projection of meshes (GT annotations): model_training/data/flame_dataset.py:115-141 (`_load_mesh`,
+ * `_project_vertices_onto_image`), visualize.py:10-22 (`get_2d_keypoints`). All DEVICE pointers:
+ *   vertices [B,nver,3], model_view [B,4,4], projection [B,4,4] (row-major, as the annotation JSON stores them),
+ *   frame [B,3] = (image height, crop_point_x, crop_point_y) -- zeros for no crop.
+ * Outputs, each optional (NULL): world_homo [B,nver,4] = (MV . [v;1])^T, xy [B,nver,2] = (x/w, H - y/w) - crop,
+ * xy_int [B,nver,2] = (int) xy. Agreement with the numpy reference is to fp32 rounding, not bitwise (sgemm order).
+ * --------------------------------------------------------------------------------------------- */
+dad3d_status dad3d_project_vertices(const float* vertices, const float* model_view, const float* projection,
+                                    const float* frame, int batch, int nver, float* world_homo, float* xy,
+                                    int32_t* xy_int, int device, void* stream);
+
 /* Single-image HOST entry points with the argument lists of Sim3DR/lib/rasterize.h:84-100 (`bool` spelled
  * `int` for C). libdad3d_hip.so additionally exports the C++-linkage symbols `_get_tri_normal`,
  * `_get_ver_normal`, `_get_normal`, `_rasterize_triangles`, `_rasterize` with the reference's exact

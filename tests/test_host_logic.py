@@ -190,3 +190,16 @@ def test_68_landmark_embedding_matches_reference_goldens(tmp_path):
     bx.write_submission(str(p), {"item_0": entry})
     back = json.loads(p.read_text())
     assert back["item_0"]["7_landmarks_3d"] == [[float(x) for x in row] for row in want7[0]]
+
+
+def test_projection_oracle_matches_reference_goldens():
+    """oracle/projection_ref.py == the reference's own visualize.get_2d_keypoints (tests/golden/make_projection_golden.py)."""
+    import os
+
+    from oracle import projection_ref
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "projection_golden.npz")) as z:
+        for i in range(3):
+            data = {"vertices": z[f"vertices_{i}"].tolist(), "model_view_matrix": z[f"model_view_{i}"].tolist(),
+                    "projection_matrix": z[f"projection_{i}"].tolist()}
+            assert np.array_equal(projection_ref.get_2d_keypoints(data, int(z[f"height_{i}"])), z[f"keypoints_{i}"])
