@@ -235,3 +235,27 @@ def test_back_to_back_rasterisations_are_stable(static, decode_golden):
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
         assert torch.equal(o, first16 if i % 2 == 0 else first5), i
+
+
+def test_config4_and_config5_batch_sizes(static, flame_model, flame_consts, port_oracle):
+    """BASELINE configs 4 and 5 at their single-node totals on ONE GPU: decode of 2048 rows (sampled against the oracle)
+    and the render chain on 512 of them (sampled bit-exact against the reference raster on the same vertices)."""
+    from dad_3dheads_amd import landmarks, synthetic
+    from dad_3dheads_amd.head_mesh import HeadMesh
+    from oracle import flame_ref
+
+    hm = HeadMesh(flame_model=flame_model, landmarks=landmarks.canonical("445", static), static=static, device=0)
+    p = torch.from_numpy(synthetic.synthetic_params(2048, seed=77)).cuda()
+    out = hm.decode(p, to_2d=False, flip_z=True, landmarks=False, landmarks_px=True)
+    idx = [0, 1, 63, 64, 1000, 2047]
+    ref = flame_ref.vertices_3d(flame_consts, p[idx].cpu().clone())
+    assert (out["verts3d"][idx].cpu() - ref).abs().max() < 5e-6
+    assert out["lmk_px"].shape == (2048, 445, 2)
+    mesh = Mesh(static["faces"], 5023, device=0)
+    verts = out["proj"][:512].contiguous()
+    light = mesh.phong_light(verts, None)
+    img = mesh.rasterize(verts, light, torch.zeros((512, 256, 256, 3), dtype=torch.uint8, device="cuda"))
+    for i in (0, 255, 511):
+        want = port_oracle.rasterize(np.ascontiguousarray(verts[i].cpu().numpy()), static["faces"],
+                                     np.ascontiguousarray(light[i].cpu().numpy()), bg=np.zeros((256, 256, 3), np.uint8))
+        assert np.array_equal(img[i].cpu().numpy(), want), i
