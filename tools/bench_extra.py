@@ -76,6 +76,34 @@ def main():
         mesh.rasterize(dec["proj"], lt, img)
 
     t_pipe = gpu_time(pipeline, iters=100)
+
+    # the same chain with two batches in flight: one forked decode handle, one mesh handle and one buffer set per stream
+    lanes = []
+    for i in range(2):
+        lanes.append({"hm": hm if i == 0 else hm.fork(), "mesh": Mesh(faces, 5023, device=0), "stream": torch.cuda.Stream(),
+                      "p": torch.from_numpy(synthetic.synthetic_params(B, seed=2 + i)).cuda(), "dec": {}, "img": torch.zeros_like(img)})
+    torch.cuda.synchronize()
+    turn = [0]
+
+    def pipeline2():
+        ln = lanes[turn[0] % 2]
+        turn[0] += 1
+        with torch.cuda.stream(ln["stream"]):
+            ln["hm"].flame.decode(ln["p"], proj=True, to_2d=False, flip_z=True, out=ln["dec"])
+            lt = ln["mesh"].phong_light(ln["dec"]["proj"], None)
+            ln["mesh"].rasterize(ln["dec"]["proj"], lt, ln["img"])
+
+    def wall(fn, iters=200, warm=20):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    t_pipe2 = wall(pipeline2)
     v0 = np.ascontiguousarray(verts[0].cpu().numpy())
     x, y = v0[:, 0][faces], v0[:, 1][faces]
     tests = float(np.sum(np.clip(np.floor(x.max(1)) - np.ceil(x.min(1)) + 1, 0, None) * np.clip(np.floor(y.max(1)) - np.ceil(y.min(1)) + 1, 0, None)))
@@ -87,6 +115,7 @@ def main():
                            "bbox_pixel_tests_image0": tests, "Gtests_per_s": tests * B / t_rast / 1e9},
         "pncc_6270": {"images_per_s": B / t_pncc, "us_per_batch": t_pncc * 1e6},
         "decode+normals+light+raster": {"images_per_s": B / t_pipe, "us_per_batch": t_pipe * 1e6},
+        "decode+normals+light+raster_two_streams": {"images_per_s": B / t_pipe2, "us_per_batch": t_pipe2 * 1e6},
     }
     # ---- CPU references ----------------------------------------------------------------------------------
     kind = "reference" if sim3dr_ref.available("reference") else "port"
