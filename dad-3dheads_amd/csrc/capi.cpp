@@ -62,7 +62,7 @@ struct dad3d_flame {
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
     int n_lmk = 0;
     float* d_imgc = nullptr;
-    unsigned* d_sync = nullptr;   // [0] arrival counter, [1] time-out counter
+    unsigned* d_sync = nullptr;   // [0] arrival counter, [1] time-out counter; [4], [5], [last]: device-epoch launches
     unsigned arrive_total = 0;    // host mirror of sync[0] after the last launch
     int cap_nbb = 0;
     bool profiling = false;
@@ -204,7 +204,7 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
     h->c->device = device;
     if ((st = upload(&h->c->d_bpack, bpack)) || (st = upload(&h->c->d_jdirs, jdirs)) || (st = upload(&h->c->d_j0, j0)) ||
         (st = upload(&h->c->d_w8, w8)) || (st = upload(&h->d_lmk_head, head)) ||
-        (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = upload(&h->d_sync, std::vector<unsigned>(4, 0u))) ||
+        (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = upload(&h->d_sync, std::vector<unsigned>(kSyncWords, 0u))) ||
         (st = flame_reserve(h.get(), 1))) {
         dad3d_flame_destroy(h.release());
         return st;
@@ -232,8 +232,8 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->d_lmk_head = h->d_lmk_next = nullptr;
     h->d_imgc = nullptr;
     h->d_sync = nullptr;
-    h->cap_nbb = 0;
     h->arrive_total = 0;
+    h->cap_nbb = 0;
     h->profiling = false;
     h->d_trace = nullptr;
     h->ev_first = h->ev_last = nullptr;
@@ -244,7 +244,7 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
         hipMalloc(reinterpret_cast<void**>(&h->d_lmk_next), std::max<size_t>(nl, 1) * sizeof(int)) != hipSuccess ||
         hipMemcpy(h->d_lmk_head, parent->d_lmk_head, nv * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess ||
         (nl && hipMemcpy(h->d_lmk_next, parent->d_lmk_next, nl * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess) ||
-        (st = upload(&h->d_sync, std::vector<unsigned>(4, 0u))) != DAD3D_OK) {
+        (st = upload(&h->d_sync, std::vector<unsigned>(kSyncWords, 0u))) != DAD3D_OK) {
         if (st == DAD3D_OK) set_error("dad3d_flame_fork: device allocation or copy failed");
         dad3d_flame_destroy(h.release());
         return st == DAD3D_OK ? DAD3D_E_HIP : st;
@@ -322,15 +322,19 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     da.max_shape = h->max_shape;
     da.betas_contiguous = (h->lay.shape_n == 300 && h->lay.expr_n == 100 && h->lay.shape_off == 0 && h->lay.expr_off == 300);
     da.kgroups = h->kgroups;
+    // a launch that is being captured into a graph cannot carry a per-launch target: the epoch then lives on the device
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
+    const bool device_epoch = capture != hipStreamCaptureStatusNone;
     da.arrive_target = h->arrive_total + (unsigned)batch;  // every image's pose wave arrives once per launch
     da.spin_limit = 1u << 20;
     da.image_size = h->image_size;
-    da.flags = flags;
+    da.flags = (flags & 0xFFu) | (device_epoch ? kDeviceEpoch : 0u);
     dad3d_status st;
 
     st = launch_flame_decode(da, s);
     if (st) return st;
-    h->arrive_total = da.arrive_target;  // committed only once the launch was accepted
+    if (!device_epoch) h->arrive_total = da.arrive_target;  // committed only once the launch was accepted
     if (h->profiling) ++h->prof_launches;
     return DAD3D_OK;
 }

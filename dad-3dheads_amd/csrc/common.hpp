@@ -55,6 +55,8 @@ constexpr int kBlockImages = 64; // images (GEMM rows) per workgroup: 4 MFMA row
 constexpr int kImgConsts = 84;   // floats per image: A_j 5x12 (jaw first) | R 9 | s tx ty | 4 compact translations
 constexpr int kNumJoints = 5;    // FLAME: global, neck, jaw, left eye, right eye
 constexpr int kOutStride = 68;   // LDS row stride of the accumulator tile (conflict-free ds_write_b32)
+constexpr int kSyncWords = 1025;  // dad3d_flame sync block: words 0..5 + the ticket in the last word
+constexpr unsigned kDeviceEpoch = 0x100u;  // internal decode flag: hand-off epoch kept on the device (graph capture)
 
 // Offsets into one params row, `FlameParams.from_3dmm` order (flame.py:48-73).
 struct ParamLayout {
@@ -79,6 +81,8 @@ struct DecodeArgs {
     const int* lmk_next;    // [n_lmk] next slot with the same vertex or -1
     float* imgc;            // [B][kImgConsts] per-image constants: pose role -> decode role hand-off
     unsigned* sync;         // [0] arrivals (monotonic over launches)  [1] hand-off time-outs (sticky)
+                            // device-epoch launches (graph capture): [4] their arrivals  [5] arrivals of all earlier
+                            // such launches (advanced by the kernel)  [kSyncWords-1] launch ticket
     float* verts3d;         // [B,V,3] or null
     float* proj;            // [B,V,2|3] or null
     float* lmk_xy;          // [B,n_lmk,2] or null
@@ -91,7 +95,7 @@ struct DecodeArgs {
     int n_betas, max_shape;  // 400, 300
     int betas_contiguous;    // params[0:400] are the betas (shape == 300 and expression == 100)
     int kgroups;
-    unsigned arrive_target;  // value of sync[0] once every image of this launch has been published
+    unsigned arrive_target;  // host-side epoch: value of sync[0] once every image of this launch has been published
     unsigned spin_limit;
     float image_size;
     unsigned flags;

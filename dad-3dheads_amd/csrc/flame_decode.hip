@@ -43,6 +43,8 @@ namespace {
 
 constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
 constexpr int kCacheSc1 = 16;          // buffer-op aux bit: write-through store / L1-bypassing load
+constexpr int kTicketWord = kSyncWords - 1;  // the per-launch workgroup ticket: 4 KiB away from the arrival counter, so
+                                             // its ~270 same-address atomics queue in another L2 channel
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -302,7 +304,7 @@ struct DecodeLds {
 // multiplies its 8 betas against it, and the 15 x 64 partial sums are reduced through LDS by 15 lanes (a 6-step
 // ds_bpermute butterfly per value measured 4x slower). Everything else is scalar math every lane does redundantly;
 // lane l < 21 then keeps float4 number l of the block and stores it write-through.
-template <bool JAW_ONLY, bool CONTIG>
+template <bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH>
 __device__ void pose_role(const DecodeArgs& a, float* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x * 4 + wave;
@@ -396,7 +398,7 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine), rsrc, lane * 16, 0, kCacheSc1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (trace && lane == 0) trace[2] = __builtin_readcyclecounter();
-    if (lane == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_fetch_add(a.sync + (DEV_EPOCH ? 4 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (trace && lane == 0) trace[3] = __builtin_readcyclecounter(), trace[13] = wall_clock64();
 }
 
@@ -421,11 +423,40 @@ struct Parts {  // A-image parts in MFMA groups of 16 k: [0,6) [6,14) [14,KG)
     static constexpr int begin(int p) { return p == 0 ? 0 : p == 1 ? 6 : p == 2 ? 14 : KG; }
 };
 
-template <int KG, bool JAW_ONLY, bool CONTIG>
+template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH>
 __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // Two ways to tell the decode role how far the arrival counter must get. Normally the HOST keeps the running
+    // total and passes the target (a.arrive_target): nothing extra happens on the device. A launch that is being
+    // captured into a hipGraph must not carry per-launch arguments, so there (kDeviceEpoch, chosen by the C API when
+    // the stream is capturing) the total lives ON THE DEVICE: sync[5] = arrivals of all earlier device-epoch launches
+    // = the value of their own arrival counter sync[4] when this launch starts (launches of one handle are
+    // stream-ordered); the decode role waits for sync[4] to reach it plus this launch's images. The epoch may advance
+    // once EVERY workgroup has read it: each workgroup takes a ticket after its read has returned, and whoever gets the
+    // last ticket writes the new epoch. One lane per workgroup does this with vector (non-blocking) accesses -- a
+    // scalar load of the epoch at the top stalled every wave of the launch for a memory round trip. The ~270
+    // same-address ticket atomics still delay the hand-off poll behind them: +1.6 us per launch, which is why the
+    // host-side target stays the default.
+    constexpr bool dev_epoch = DEV_EPOCH;  // compile-time: the default instantiation carries none of this
+    unsigned* arrivals = a.sync + (dev_epoch ? 4 : 0);
+    auto read_epoch = [&]() { return __hip_atomic_load(a.sync + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto take_ticket = [&]() { return __hip_atomic_fetch_add(a.sync + kTicketWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto advance_epoch_if_last = [&](unsigned ticket, unsigned epoch_base) {
+        if (ticket == gridDim.x - 1) {
+            __hip_atomic_store(a.sync + kTicketWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 5, epoch_base + (unsigned)a.batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto bystander = [&]() {  // a workgroup that does not consume the hand-off: thread 511 (idle in the pose role)
+        if (dev_epoch && threadIdx.x == 511) {
+            const unsigned eb = read_epoch();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the read has returned before the ticket is taken
+            advance_epoch_if_last(take_ticket(), eb);
+        }
+    };
     if ((int)blockIdx.x < a.n_pose_blocks_pad8) {
-        if ((int)blockIdx.x < a.n_pose_blocks && threadIdx.x < 256) pose_role<JAW_ONLY, CONTIG>(a, smem);
+        bystander();
+        if ((int)blockIdx.x < a.n_pose_blocks && threadIdx.x < 256) pose_role<JAW_ONLY, CONTIG, DEV_EPOCH>(a, smem);
         return;
     }
     using L = DecodeLds<KG>;
@@ -445,7 +476,10 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     const int xcd = gid & 7, rr = gid >> 3;
     const int bb = rr % a.nbb;
     const int tile = (rr / a.nbb) * 8 + xcd;
-    if (tile >= a.n_tiles) return;
+    if (tile >= a.n_tiles) {
+        bystander();
+        return;
+    }
     unsigned long long* trace = a.trace ? a.trace + ((size_t)gid * 8 + wave) * 32 : nullptr;
     auto stamp = [&](int slot) {
         if (trace && lane == 0) trace[slot] = __builtin_readcyclecounter();
@@ -573,6 +607,9 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     }
         DAD3D_LOAD_PART(0)
         DAD3D_LOAD_PART(1)
+        // requested behind the first parts (vector loads return in order: nothing the GEMM needs waits for it)
+        unsigned epoch_base = 0;
+        if (dev_epoch && wave == 4 && lane == 0) epoch_base = read_epoch();
         // pose inputs of image (16*(wave-4) + lane) for the A rows past the betas; per-vertex constants
         PoseIn pose_in{};
         const int trow = (wave - 4) * 16 + lane;
@@ -640,16 +677,19 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         // workgroup with a short sleep measurably slowed the pose role they were waiting for), generous sleep
         // between polls; the other feeder waves wait on an LDS flag.
         if (wave == 4 && lane == 0) {
+            const unsigned ticket = dev_epoch ? take_ticket() : 0u;  // epoch_base is back (older than part 2's loads)
+            const unsigned target = dev_epoch ? epoch_base + (unsigned)a.batch : a.arrive_target;
             int st = 2;
             for (unsigned spin = 0; spin < a.spin_limit; ++spin) {
-                const unsigned seen = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(seen - a.arrive_target) >= 0) {
+                const unsigned seen = __hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(seen - target) >= 0) {  // every image's pose wave arrives once per launch
                     st = 1;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(10);
             }
             __hip_atomic_store(handoff_flag, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (dev_epoch) advance_epoch_if_last(ticket, epoch_base);  // its round trip overlapped the polling
         }
         while (lds_peek(handoff_flag) == 0) __builtin_amdgcn_s_sleep(4);
         const int ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
@@ -785,19 +825,25 @@ size_t flame_decode_lds_bytes(int kgroups) {
     return (size_t)(kgroups == 26 ? DecodeLds<26>::total : DecodeLds<28>::total) * sizeof(float);
 }
 
-template <int KG, bool JAW_ONLY, bool CONTIG>
-static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
+template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH>
+static dad3d_status launch_decode_e(const DecodeArgs& a, hipStream_t s) {
     static bool attr_done = false;
     const size_t lds = flame_decode_lds_bytes(KG);
     if (!attr_done) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG, JAW_ONLY, CONTIG>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8 * a.nbb;
-    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH>), dim3(grid), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
+}
+
+template <int KG, bool JAW_ONLY, bool CONTIG>
+static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
+    return (a.flags & kDeviceEpoch) ? launch_decode_e<KG, JAW_ONLY, CONTIG, true>(a, s)
+                                    : launch_decode_e<KG, JAW_ONLY, CONTIG, false>(a, s);
 }
 
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s) {

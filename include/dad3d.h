@@ -96,7 +96,11 @@ int dad3d_flame_num_landmarks(const dad3d_flame* h);
  *                       (always rotated; DAD3D_ZERO_ROTATION applies to verts3d only, as in the reference)
  *   lmk_xy  [B,n,2] fp32 = proj[:, idx, :2]
  *   lmk_px  [B,n,2] int32 = projected.astype(int)[idx]  (truncation)           demo_utils.py:42,46
- * The reference needs two full decodes for verts3d + proj (predictor.py:136-137); this is one. */
+ * The reference needs two full decodes for verts3d + proj (predictor.py:136-137); this is one.
+ * hipGraph: the call may be captured (hipStreamBeginCapture on `stream`) after one warm-up call with the same batch
+ * size; a captured launch keeps its hand-off bookkeeping on the device, so the graph can be replayed any number of
+ * times and interleaved with direct calls (about 1.6 us slower per launch than a direct call). The raster and
+ * lighting entry points below are capturable as they are (warm up once with the same shapes). */
 dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                 float* lmk_xy, int32_t* lmk_px, void* stream);
 

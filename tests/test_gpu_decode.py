@@ -267,3 +267,47 @@ def test_forked_handles_on_two_streams_match_oracle(flame_model, flame_consts, s
     hm_c.set_landmarks(idx[:10])
     assert hm_c.decode(pb, landmarks=False, landmarks_px=True)["lmk_px"].shape == (40, 10, 2)
     assert hm_b.decode(pb, landmarks=False, landmarks_px=True)["lmk_px"].shape == (40, 445, 2)
+
+
+def test_decode_and_render_chain_replay_from_a_hip_graph(flame_model, flame_consts, static):
+    """The launches carry no per-launch host state (the hand-off epoch lives on the device, the raster queue resets
+    itself), so a captured graph -- decode, normals + light, geometry, raster -- can be replayed with new parameter
+    VALUES in the same buffers. Every replay must match an eager run on the same values."""
+    from dad_3dheads_amd.Sim3DR import Mesh
+
+    hm = HeadMesh(flame_model=flame_model, landmarks=landmarks.canonical("445", static), static=static, device=0)
+    mesh = Mesh(static["faces"], 5023, device=0)
+    b = 24
+    p = torch.from_numpy(synthetic.synthetic_params(b, seed=50)).cuda()
+    dec, img = {}, torch.zeros((b, 256, 256, 3), dtype=torch.uint8, device="cuda")
+
+    def chain():
+        img.zero_()
+        hm.decode(p, to_2d=False, flip_z=True, landmarks=False, landmarks_px=True, out=dec)
+        light = mesh.phong_light(dec["proj"], None)
+        mesh.rasterize(dec["proj"], light, img)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):  # warm-up: scratch buffers are allocated outside the capture
+            chain()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        chain()
+    for seed in (51, 52, 53, 54):
+        new = torch.from_numpy(synthetic.synthetic_params(b, seed=seed)).cuda()
+        p.copy_(new)
+        graph.replay()
+        torch.cuda.synchronize()
+        got_v, got_l, got_img = dec["verts3d"].clone(), dec["lmk_px"].clone(), img.clone()
+        ref = flame_ref.vertices_3d(flame_consts, new.cpu().clone())
+        assert (got_v.cpu() - ref).abs().max() < TOL_V
+        p.copy_(new)
+        chain()  # eager, same values
+        torch.cuda.synchronize()
+        assert torch.equal(dec["verts3d"], got_v) and torch.equal(dec["lmk_px"], got_l) and torch.equal(img, got_img)
+        assert got_img.any()
+    n = C.c_uint()
+    _lib.check(_lib.load().dad3d_flame_handoff_timeouts(hm.flame._handle, C.byref(n)))
+    assert n.value == 0
