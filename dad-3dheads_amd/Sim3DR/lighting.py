@@ -56,13 +56,15 @@ class RenderPipeline(object):
         dev = mesh.torch_device
         v = torch.from_numpy(np.ascontiguousarray(vertices, dtype=np.float32)).to(dev)[None]
         img = torch.from_numpy(bg).to(dev)[None].contiguous()
-        light = mesh.phong_light(v, None, **self._light_kwargs())  # vertex normals + Phong terms in one launch
-        if texture is None:
-            colors = light
+        if texture is None and img.shape[-1] == 3:
+            mesh.render(v, img, **self._light_kwargs())  # normals + Phong inside the raster's geometry kernel: two launches
         else:
-            tex = torch.from_numpy(np.ascontiguousarray(texture, dtype=np.float32)).to(dev)[None] * light
-            texture[...] = tex[0].cpu().numpy()  # `texture *= light` is in place in the reference (lighting.py:69)
-            colors = tex.contiguous()
-        mesh.rasterize(v, colors, img)
+            light = mesh.phong_light(v, None, **self._light_kwargs())  # vertex normals + Phong terms in one launch
+            colors = light
+            if texture is not None:
+                tex = torch.from_numpy(np.ascontiguousarray(texture, dtype=np.float32)).to(dev)[None] * light
+                texture[...] = tex[0].cpu().numpy()  # `texture *= light` is in place in the reference (lighting.py:69)
+                colors = tex.contiguous()
+            mesh.rasterize(v, colors, img)
         bg[...] = img[0].cpu().numpy()  # the reference renders into `bg` and returns it
         return bg

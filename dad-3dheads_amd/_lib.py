@@ -87,6 +87,7 @@ SIGNATURES = {
     "dad3d_mesh_rasterize_triangles": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dad3d_mesh_phong_light": (_I, [_P, _P, _P, _P, _I, C.POINTER(LightC), _P]),
     "dad3d_mesh_normal_phong_light": (_I, [_P, _P, _P, _P, _I, C.POINTER(LightC), _P]),
+    "dad3d_mesh_render": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LightC), _I, _P]),
     "dad3d_mesh_debug_trace": (_I, [_P, _P]),
     "dad3d_project_vertices": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "dad3d_sim3dr_get_tri_normal": (None, [_P, _P, _P, _I, _I]),

@@ -217,6 +217,122 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m
 }
 
 // ------------------------------------------------------------------------------------------------
+// Phong vertex lighting (Sim3DR/lighting.py:37-62)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// Lights the vertices [v0, v_end) of image b (stride kStageThreads): lv = the image's vertices in LDS (already staged and
+// barrier-ed), red = 6 x 16 floats of LDS scratch, row = the prefetched incidence row of vertex v0 (FUSE_NORMALS).
+template <bool FUSE_NORMALS>
+__device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const float* lv, float (*red)[kStageThreads / 64], size_t b,
+                                                  int v0, int v_end, AdjRow row, float* light, const float* normals,
+                                                  float* normals_out, int nver, const dad3d_light& cfg) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float bd[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int u = tid; u < nver; u += kStageThreads)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = lv[3 * u + k];
+            bd[k] = fminf(bd[k], x);
+            bd[3 + k] = fmaxf(bd[3 + k], x);
+        }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_xor(bd[k], o);
+            bd[k] = k < 3 ? fminf(bd[k], other) : fmaxf(bd[k], other);
+        }
+        if (lane == 0) red[k][wave] = bd[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float r = red[k][0];
+        for (int wv = 1; wv < kStageThreads / 64; ++wv) r = k < 3 ? fminf(r, red[k][wv]) : fmaxf(r, red[k][wv]);
+        bd[k] = r;
+    }
+    // norm_vertices (lighting.py:9-14): v -= min(0); v /= max(); v *= 2; v -= max(0)/2
+    float ext[3], gmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ext[k] = bd[3 + k] - bd[k];
+        gmax = fmaxf(gmax, ext[k]);
+    }
+    for (int v = v0; v < v_end; v += kStageThreads) {
+    AdjRow cur;
+    if (FUSE_NORMALS) {
+        cur = row;
+        row = load_adj_row(m, v + kStageThreads, v + kStageThreads < v_end);
+    }
+    float vn[3], n[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x = lv[3 * v + k];
+        const float amax = ext[k] / gmax * 2.0f;
+        vn[k] = (x - bd[k]) / gmax * 2.0f - amax / 2.0f;
+        n[k] = FUSE_NORMALS ? 0.0f : normals[(b * nver + v) * 3 + k];
+    }
+    if (FUSE_NORMALS) {
+        add_incident_faces(m, lv, cur, n);
+        unit3(n);
+        if (normals_out)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) normals_out[(b * nver + v) * 3 + k] = n[k];
+    }
+    float out[3] = {0.0f, 0.0f, 0.0f};
+    if (cfg.intensity_ambient > 0.0f)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] += cfg.intensity_ambient * cfg.color_ambient[k];
+    if (cfg.intensity_directional > 0.0f) {
+        float d[3] = {cfg.light_pos[0] - vn[0], cfg.light_pos[1] - vn[1], cfg.light_pos[2] - vn[2]};
+        const float dl = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] /= dl, d[1] /= dl, d[2] /= dl;
+        const float cosv = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] += cfg.intensity_directional * (cfg.color_directional[k] * clip01(cosv));
+        if (cfg.intensity_specular > 0.0f) {
+            float e[3] = {cfg.view_pos[0] - vn[0], cfg.view_pos[1] - vn[1], cfg.view_pos[2] - vn[2]};
+            const float el = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            e[0] /= el, e[1] /= el, e[2] /= el;
+            float spe = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float refl = 2.0f * cosv * n[k] - d[k];
+                spe += powf(e[k] * refl, cfg.specular_exp);
+            }
+            spe = (cosv != 0.0f) ? clip01(spe) : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] += cfg.intensity_specular * cfg.color_directional[k] * clip01(spe);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) light[(b * nver + v) * 3 + k] = clip01(out[k]);
+    }
+}
+
+
+// One launch: block = (vertex chunk, image). The image's vertices are staged in LDS, every block reduces the per-axis
+// min / max of the whole image itself (norm_vertices, lighting.py:9-14: exact whatever the reduction order), then lights
+// its chunk. FUSE_NORMALS: the vertex normals are computed here from the staged vertices (_get_normal on a zeroed
+// buffer, as RenderPipeline does, lighting.py:64-66) instead of being read back; `normals_out` (optional) gets them.
+template <bool FUSE_NORMALS>
+__global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* light, const float* vertices,
+                                                              const float* normals, float* normals_out, int nver,
+                                                              dad3d_light cfg, int verts_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_p[];
+    __shared__ float red[6][kStageThreads / 64];
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const int v_end = min(nver, ((int)blockIdx.x + 1) * verts_per_block);
+    const int v0 = blockIdx.x * verts_per_block + tid;
+    AdjRow row{};
+    if (FUSE_NORMALS) row = load_adj_row(m, v0, v0 < v_end);  // in flight while the vertices are staged
+    const float* lv = stage_floats(lds_p, vertices + b * nver * 3, nver * 3, tid);
+    __syncthreads();
+    phong_light_chunk<FUSE_NORMALS>(m, lv, red, b, v0, v_end, row, light, normals, normals_out, nver, cfg);
+}
+
+// ------------------------------------------------------------------------------------------------
 // rasterisation
 // ------------------------------------------------------------------------------------------------
 // Two launches per batch:
@@ -330,9 +446,17 @@ __device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned*
 #ifndef DAD3D_K1_ABLATE  // diagnostics only (tools/k1_ablate.sh): 1 no LDS binning atomics, 2 no list writes, 4 no records
 #define DAD3D_K1_ABLATE 0
 #endif
-template <bool LDS_VERTS>
+// WITH_LIGHT (RenderPipeline in two launches): before the triangles, the block lights its share of the image's vertices
+// from the same LDS copy -- vertex normals, norm_vertices bounds and the Phong terms of lighting.py:41-62 -- into
+// `light`, which the raster kernel then reads as the colours. Saves the lighting kernel's own staging and launch.
+struct LightJob {
+    float* light;  // [B][nver][3]
+    dad3d_light cfg;
+};
+
+template <bool LDS_VERTS, bool WITH_LIGHT>
 __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, const float* vertices, RasterScratch sc,
-                                                                   int h, int w) {
+                                                                   int h, int w, LightJob job) {
     extern __shared__ __attribute__((aligned(16))) float lds_v[];
     const int tid = threadIdx.x;
     const size_t b = blockIdx.y;
@@ -344,6 +468,14 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     for (int t = tid; t < 2 * ntiles; t += kGeoThreads) cnt[t] = 0;
     const float* lv = LDS_VERTS ? stage_floats(lds_v, vb, n, tid) : nullptr;
     __syncthreads();
+    if (WITH_LIGHT) {
+        static_assert(!WITH_LIGHT || LDS_VERTS, "lighting needs the staged vertices");
+        __shared__ float red[6][kStageThreads / 64];
+        const int vpb = (m.nver + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lv0 = blockIdx.x * vpb + tid, lv_end = min(m.nver, ((int)blockIdx.x + 1) * vpb);
+        phong_light_chunk<true>(m, lv, red, b, lv0, lv_end, load_adj_row(m, lv0, lv0 < lv_end), job.light, nullptr, nullptr,
+                                m.nver, job.cfg);
+    }
     auto coord = [&](int e) { return LDS_VERTS ? lv[e] : vb[e]; };
     const size_t nt = m.ntri;
     uint2 box[kGeoPerThread];
@@ -808,112 +940,6 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Phong vertex lighting (Sim3DR/lighting.py:37-62)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
-
-// One launch: block = (vertex chunk, image). The image's vertices are staged in LDS, every block reduces the per-axis
-// min / max of the whole image itself (norm_vertices, lighting.py:9-14: exact whatever the reduction order), then lights
-// its chunk. Replaces a one-block-per-image bounds kernel (9 us, latency-bound) plus a lighting kernel.
-// FUSE_NORMALS: the vertex normals are computed here from the staged vertices (_get_normal on a zeroed buffer, as
-// RenderPipeline does, lighting.py:64-66) instead of being read back; `normals_out` (optional) receives them.
-template <bool FUSE_NORMALS>
-__global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* light, const float* vertices,
-                                                              const float* normals, float* normals_out, int nver,
-                                                              dad3d_light cfg, int verts_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds_p[];
-    __shared__ float red[6][kStageThreads / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t b = blockIdx.y;
-    const int v_end = min(nver, ((int)blockIdx.x + 1) * verts_per_block);
-    const int v0 = blockIdx.x * verts_per_block + tid;
-    AdjRow row;
-    if (FUSE_NORMALS) row = load_adj_row(m, v0, v0 < v_end);  // in flight while the vertices are staged
-    const float* lv = stage_floats(lds_p, vertices + b * nver * 3, nver * 3, tid);
-    __syncthreads();
-    float bd[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int u = tid; u < nver; u += kStageThreads)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float x = lv[3 * u + k];
-            bd[k] = fminf(bd[k], x);
-            bd[3 + k] = fmaxf(bd[3 + k], x);
-        }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        for (int o = 32; o > 0; o >>= 1) {
-            const float other = __shfl_xor(bd[k], o);
-            bd[k] = k < 3 ? fminf(bd[k], other) : fmaxf(bd[k], other);
-        }
-        if (lane == 0) red[k][wave] = bd[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        float r = red[k][0];
-        for (int wv = 1; wv < kStageThreads / 64; ++wv) r = k < 3 ? fminf(r, red[k][wv]) : fmaxf(r, red[k][wv]);
-        bd[k] = r;
-    }
-    // norm_vertices (lighting.py:9-14): v -= min(0); v /= max(); v *= 2; v -= max(0)/2
-    float ext[3], gmax = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        ext[k] = bd[3 + k] - bd[k];
-        gmax = fmaxf(gmax, ext[k]);
-    }
-    for (int v = v0; v < v_end; v += kStageThreads) {
-    AdjRow cur;
-    if (FUSE_NORMALS) {
-        cur = row;
-        row = load_adj_row(m, v + kStageThreads, v + kStageThreads < v_end);
-    }
-    float vn[3], n[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float x = lv[3 * v + k];
-        const float amax = ext[k] / gmax * 2.0f;
-        vn[k] = (x - bd[k]) / gmax * 2.0f - amax / 2.0f;
-        n[k] = FUSE_NORMALS ? 0.0f : normals[(b * nver + v) * 3 + k];
-    }
-    if (FUSE_NORMALS) {
-        add_incident_faces(m, lv, cur, n);
-        unit3(n);
-        if (normals_out)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) normals_out[(b * nver + v) * 3 + k] = n[k];
-    }
-    float out[3] = {0.0f, 0.0f, 0.0f};
-    if (cfg.intensity_ambient > 0.0f)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out[k] += cfg.intensity_ambient * cfg.color_ambient[k];
-    if (cfg.intensity_directional > 0.0f) {
-        float d[3] = {cfg.light_pos[0] - vn[0], cfg.light_pos[1] - vn[1], cfg.light_pos[2] - vn[2]};
-        const float dl = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        d[0] /= dl, d[1] /= dl, d[2] /= dl;
-        const float cosv = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out[k] += cfg.intensity_directional * (cfg.color_directional[k] * clip01(cosv));
-        if (cfg.intensity_specular > 0.0f) {
-            float e[3] = {cfg.view_pos[0] - vn[0], cfg.view_pos[1] - vn[1], cfg.view_pos[2] - vn[2]};
-            const float el = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-            e[0] /= el, e[1] /= el, e[2] /= el;
-            float spe = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float refl = 2.0f * cosv * n[k] - d[k];
-                spe += powf(e[k] * refl, cfg.specular_exp);
-            }
-            spe = (cosv != 0.0f) ? clip01(spe) : 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) out[k] += cfg.intensity_specular * cfg.color_directional[k] * clip01(spe);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) light[(b * nver + v) * 3 + k] = clip01(out[k]);
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1003,7 +1029,8 @@ dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int
 
 dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image,
                               const float* vertices, const float* colors, float* depth, int32_t* tri_buf, float* bary,
-                              int batch, int h, int w, int c, int reverse, int mode, hipStream_t s) {
+                              int batch, int h, int w, int c, int reverse, int mode, const dad3d_light* light_cfg,
+                              hipStream_t s) {
     if (batch == 0 || h == 0 || w == 0 || m.ntri == 0) return DAD3D_OK;  // nothing to draw: buffers stay as they are
     const size_t nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
     DAD3D_REQUIRE(h <= 65535 && w <= 65535 && tiles_of(h) * tiles_of(w) <= kMaxTiles && nlists < (1u << 24),
@@ -1012,9 +1039,11 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
     DAD3D_REQUIRE((unsigned)m.ntri <= kIdMask, "rasterize: more than 2^28 triangles");
     DAD3D_REQUIRE(scratch, "rasterize: no scratch buffer");
     static int persistent_blocks[2] = {0, 0};
-    constexpr int kMaxLds = 160 * 1024 - 256;  // dynamic part: the geometry kernel also has a few static words
+    constexpr int kMaxLds = 160 * 1024 - 1024;  // dynamic part: the geometry kernel also has some static words
     if (!persistent_blocks[0]) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         int dev = 0, cus = 0, per_cu[2] = {0, 0};
         DAD3D_HIP_TRY(hipGetDevice(&dev));
@@ -1034,10 +1063,17 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
         const dim3 ggrid((m.ntri + kGeoTrisPerBlock - 1) / kGeoTrisPerBlock, batch);
         const size_t cnt_bytes = std::max<size_t>(2 * (size_t)ntiles, kQueueBuckets) * sizeof(unsigned);  // counters, later the queue histogram
         const size_t vlds = ((size_t)m.nver * 3 + 12) * sizeof(float) + cnt_bytes;
-        if (vlds <= (size_t)kMaxLds)
-            hipLaunchKernelGGL(tri_geometry_kernel<true>, ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w);
-        else
-            hipLaunchKernelGGL(tri_geometry_kernel<false>, ggrid, dim3(kGeoThreads), 48 + cnt_bytes, s, m, vertices, sc, h, w);
+        LightJob job{};
+        if (light_cfg) {  // colours = per-vertex Phong light computed by the geometry kernel itself
+            DAD3D_REQUIRE(vlds <= (size_t)kMaxLds && c == 3 && mode == 0, "render: needs a 3-channel image and a mesh that fits the LDS");
+            job.light = const_cast<float*>(colors);
+            job.cfg = *light_cfg;
+            hipLaunchKernelGGL((tri_geometry_kernel<true, true>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
+        } else if (vlds <= (size_t)kMaxLds) {
+            hipLaunchKernelGGL((tri_geometry_kernel<true, false>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
+        } else {
+            hipLaunchKernelGGL((tri_geometry_kernel<false, false>), ggrid, dim3(kGeoThreads), 48 + cnt_bytes, s, m, vertices, sc, h, w, job);
+        }
         DAD3D_HIP_TRY(hipGetLastError());
     }
     RasterArgs a{m, sc, image, colors, depth, tri_buf, bary, trace, h, w, c, reverse};

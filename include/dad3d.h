@@ -194,6 +194,13 @@ dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* v
  * tiles = ceil(w/64) * ceil(h/64). */
 dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer);
 
+/* `RenderPipeline.__call__` with texture=None (Sim3DR/lighting.py:64-71) for a batch, in TWO launches: the geometry kernel
+ * of the raster also computes the vertex normals and the Phong light of its share of the vertices (same arithmetic as
+ * dad3d_mesh_normal_phong_light) into `light` [B,nver,3], the tile kernel rasterises with `light` as the colours into the
+ * 3-channel `image` [B,h,w,3]. `depth` as in dad3d_mesh_rasterize. */
+dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* vertices, float* light, float* depth, int batch,
+                               int h, int w, const dad3d_light* cfg, int reverse, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Matrix projection of meshes (GT annotations): model_training/data/flame_dataset.py:115-141 (`_load_mesh`,
  * `_project_vertices_onto_image`), visualize.py:10-22 (`get_2d_keypoints`). All DEVICE pointers:

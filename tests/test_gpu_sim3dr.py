@@ -142,6 +142,12 @@ def test_render_pipeline_matches_numpy_lighting(static, decode_golden, port_orac
     assert torch.equal(n_out, normals) and np.array_equal(fused[0].cpu().numpy(), light)
     b8 = dv.expand(8, -1, -1).contiguous() * torch.linspace(0.9, 1.1, 8, device="cuda")[:, None, None]
     assert torch.equal(mesh.phong_light(b8, None), mesh.phong_light(b8, mesh.get_normal(b8)))
+    # two-launch render (lighting inside the raster's geometry kernel) == light then rasterize, bit for bit
+    want_light = mesh.phong_light(b8, None)
+    want_img = mesh.rasterize(b8, want_light, torch.zeros((8, 256, 256, 3), dtype=torch.uint8, device="cuda"))
+    got_light = torch.empty_like(b8)
+    got_img = mesh.render(b8, torch.zeros((8, 256, 256, 3), dtype=torch.uint8, device="cuda"), light_out=got_light)
+    assert torch.equal(got_light, want_light) and torch.equal(got_img, want_img) and got_img.any()
     diff = np.abs(img.astype(int) - ref_img.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02  # coverage identical, colours within one LSB
     assert np.array_equal(img.sum(-1) > 0, ref_img.sum(-1) > 0)

@@ -76,12 +76,21 @@ def main():
         mesh.rasterize(dec["proj"], lt, img)
 
     t_pipe = gpu_time(pipeline, iters=100)
+    lbuf = torch.empty_like(verts)
+
+    def pipeline3():  # three launches: decode, geometry (+ normals + light), tiles
+        hm.flame.decode(p, proj=True, to_2d=False, flip_z=True, out=dec)
+        mesh.render(dec["proj"], img, light_out=lbuf)
+
+    t_pipe3 = gpu_time(pipeline3, iters=100)
+    t_render = gpu_time(lambda: mesh.render(verts, img, light_out=lbuf))
 
     # the same chain with two batches in flight: one forked decode handle, one mesh handle and one buffer set per stream
     lanes = []
     for i in range(2):
         lanes.append({"hm": hm if i == 0 else hm.fork(), "mesh": Mesh(faces, 5023, device=0), "stream": torch.cuda.Stream(),
-                      "p": torch.from_numpy(synthetic.synthetic_params(B, seed=2 + i)).cuda(), "dec": {}, "img": torch.zeros_like(img)})
+                      "p": torch.from_numpy(synthetic.synthetic_params(B, seed=2 + i)).cuda(), "dec": {}, "img": torch.zeros_like(img),
+                      "light": torch.empty_like(verts)})
     torch.cuda.synchronize()
     turn = [0]
 
@@ -90,8 +99,7 @@ def main():
         turn[0] += 1
         with torch.cuda.stream(ln["stream"]):
             ln["hm"].flame.decode(ln["p"], proj=True, to_2d=False, flip_z=True, out=ln["dec"])
-            lt = ln["mesh"].phong_light(ln["dec"]["proj"], None)
-            ln["mesh"].rasterize(ln["dec"]["proj"], lt, ln["img"])
+            ln["mesh"].render(ln["dec"]["proj"], ln["img"], light_out=ln["light"])
 
     def wall(fn, iters=200, warm=20):
         for _ in range(warm):
@@ -115,6 +123,8 @@ def main():
                            "bbox_pixel_tests_image0": tests, "Gtests_per_s": tests * B / t_rast / 1e9},
         "pncc_6270": {"images_per_s": B / t_pncc, "us_per_batch": t_pncc * 1e6},
         "decode+normals+light+raster": {"images_per_s": B / t_pipe, "us_per_batch": t_pipe * 1e6},
+        "render_two_launches": {"images_per_s": B / t_render, "us_per_batch": t_render * 1e6},
+        "decode+render_three_launches": {"images_per_s": B / t_pipe3, "us_per_batch": t_pipe3 * 1e6},
         "decode+normals+light+raster_two_streams": {"images_per_s": B / t_pipe2, "us_per_batch": t_pipe2 * 1e6},
     }
     # ---- CPU references ----------------------------------------------------------------------------------
