@@ -632,11 +632,22 @@ int compat_device() {
     return e ? std::atoi(e) : 0;
 }
 
+// Content hash of the triangle list (the reference API re-passes it on every call): 8 bytes per step, four
+// independent lanes -- a byte-wise FNV over 120 KB cost more than the kernels it guards.
 uint64_t fnv1a(const void* p, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(p);
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
-    return h;
+    uint64_t h[4] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        for (int k = 0; k < 4; ++k) {
+            uint64_t w;
+            std::memcpy(&w, b + i + 8 * k, 8);
+            h[k] = (h[k] ^ w) * 1099511628211ull;
+            h[k] ^= h[k] >> 29;
+        }
+    uint64_t t = n;
+    for (; i < n; ++i) t = (t ^ b[i]) * 1099511628211ull;
+    return ((h[0] * 31 + h[1]) * 31 + h[2]) * 31 + h[3] + t * 0x9E3779B97F4A7C15ull;
 }
 
 int max_index_plus_one(const int* tri, int ntri) {
@@ -658,12 +669,37 @@ dad3d_mesh* cached_mesh(const int* tri, int ntri, int nver) {
     return g_cache.mesh;
 }
 
+// Staging buffers of the single-image host entry points: a few grow-only device buffers kept for the life of the process
+// (a hipMalloc + hipFree per call cost more than the kernels; calls are serialised by g_cache.mu). A DevBuf takes the next
+// free slot of the arena; the arena is rewound when the call returns.
+struct StagingArena {
+    static constexpr int kSlots = 4;
+    void* buf[kSlots] = {};
+    size_t cap[kSlots] = {};
+    int next = 0;
+    ~StagingArena() { /* process teardown: leak on purpose, see HostMeshCache */ }
+};
+StagingArena g_arena;
+
 struct DevBuf {
     void* p = nullptr;
-    bool alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 4)) == hipSuccess; }
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    bool alloc(size_t bytes) {
+        if (g_arena.next >= StagingArena::kSlots) return false;
+        const int s = g_arena.next++;
+        bytes = std::max<size_t>(bytes, 4);
+        if (g_arena.cap[s] < bytes) {
+            if (g_arena.buf[s]) (void)hipFree(g_arena.buf[s]);
+            g_arena.buf[s] = nullptr, g_arena.cap[s] = 0;
+            if (hipMalloc(&g_arena.buf[s], bytes) != hipSuccess) return false;
+            g_arena.cap[s] = bytes;
+        }
+        p = g_arena.buf[s];
+        return true;
     }
+};
+struct ArenaScope {  // declared after the lock in every entry point
+    ArenaScope() { g_arena.next = 0; }
+    ~ArenaScope() { g_arena.next = 0; }
 };
 
 bool h2d(void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; }
@@ -676,6 +712,7 @@ extern "C" {
 void dad3d_sim3dr_get_tri_normal(float* tri_normal, float* vertices, int* triangles, int ntri, int norm_flg) {
     if (ntri <= 0) return;
     std::lock_guard<std::mutex> lock(g_cache.mu);
+    ArenaScope arena_scope;
     const int nver = max_index_plus_one(triangles, ntri);
     dad3d_mesh* m = cached_mesh(triangles, ntri, nver);
     if (!m) return;
@@ -690,6 +727,7 @@ void dad3d_sim3dr_get_tri_normal(float* tri_normal, float* vertices, int* triang
 void dad3d_sim3dr_get_ver_normal(float* ver_normal, float* tri_normal, int* triangles, int nver, int ntri) {
     if (nver <= 0) return;
     std::lock_guard<std::mutex> lock(g_cache.mu);
+    ArenaScope arena_scope;
     dad3d_mesh* m = cached_mesh(triangles, std::max(ntri, 0), nver);
     if (!m) return;
     DeviceGuard guard(m->device);
@@ -704,6 +742,7 @@ void dad3d_sim3dr_get_ver_normal(float* ver_normal, float* tri_normal, int* tria
 void dad3d_sim3dr_get_normal(float* ver_normal, float* vertices, int* triangles, int nver, int ntri) {
     if (nver <= 0) return;
     std::lock_guard<std::mutex> lock(g_cache.mu);
+    ArenaScope arena_scope;
     dad3d_mesh* m = cached_mesh(triangles, std::max(ntri, 0), nver);
     if (!m) return;
     DeviceGuard guard(m->device);
@@ -719,6 +758,7 @@ void dad3d_sim3dr_rasterize_triangles(float* vertices, int* triangles, float* de
                                       float* barycentric_weight, int ntri, int h, int w) {
     if (ntri <= 0 || h <= 0 || w <= 0) return;
     std::lock_guard<std::mutex> lock(g_cache.mu);
+    ArenaScope arena_scope;
     const int nver = max_index_plus_one(triangles, ntri);
     dad3d_mesh* m = cached_mesh(triangles, ntri, nver);
     if (!m) return;
@@ -739,6 +779,7 @@ void dad3d_sim3dr_rasterize(unsigned char* image, float* vertices, int* triangle
                             int ntri, int h, int w, int c, float alpha, int reverse) {
     if (ntri <= 0 || h <= 0 || w <= 0) return;
     std::lock_guard<std::mutex> lock(g_cache.mu);
+    ArenaScope arena_scope;
     const int nver = max_index_plus_one(triangles, ntri);
     dad3d_mesh* m = cached_mesh(triangles, ntri, nver);
     if (!m) return;
