@@ -83,13 +83,13 @@ class FaceMeshPredictor:
         return cls(config=load_default_config(), **kwargs)
 
     @classmethod
-    def random_init(cls, dtype: torch.dtype = torch.bfloat16, seed: int = 0, **kwargs):
+    def random_init(cls, dtype: torch.dtype = torch.bfloat16, seed: int = 0, tune: bool = False, **kwargs):
         """DAD-3DNet architecture declared in `network.py` with seeded random weights (no checkpoint offline):
         the real compute and memory footprint of the front half for throughput and plumbing tests."""
         from .config import load_default_config
         from .network import DAD3DNet, InferenceNet
 
-        return cls(config=load_default_config(), model=InferenceNet(DAD3DNet(seed=seed), dtype), **kwargs)
+        return cls(config=load_default_config(), model=InferenceNet(DAD3DNet(seed=seed), dtype, tune=tune), **kwargs)
 
     # -- preprocess (predictor.py:86-95,195-203) ---------------------------------------------------------
     def _geometry(self, hw: Tuple[int, int]) -> Tuple[List[int], float, Tuple[int, int]]:

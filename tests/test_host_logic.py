@@ -111,6 +111,23 @@ def test_dad3dnet_declaration_matches_the_reference_output_contract():
     assert out["3dmm_params"][:, :403].abs().max() <= 3.0 and (out["2d_landmarks"] >= 0).all()
     again = InferenceNet(DAD3DNet(seed=0), torch.float32)(torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)))
     assert torch.equal(out["3dmm_params"], again["3dmm_params"])  # seeded initialisation
+    # BatchNorm folding is an exact rewrite up to rounding (non-trivial statistics to make it a real check)
+    raw = DAD3DNet(seed=0).eval()
+    g = torch.Generator().manual_seed(3)
+    for mod in raw.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    import copy
+
+    xin = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(1))
+    ref = InferenceNet(copy.deepcopy(raw), torch.float32, fold_bn=False)(xin)
+    folded = InferenceNet(raw, torch.float32, fold_bn=True)(xin)
+    assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in raw.modules())
+    for k in ref:
+        assert torch.allclose(ref[k], folded[k], atol=2e-3, rtol=1e-3), k
 
 
 def test_obj_and_json_writers_produce_the_reference_bytes(tmp_path):

@@ -32,7 +32,7 @@ def main():
     model = synthetic.synthetic_flame_model(0, st)
     out = {"batch": batch, "data": "synthetic uint8 256x256x3, random-init weights"}
     for name, dtype in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
-        pred = FaceMeshPredictor.random_init(dtype=dtype, cuda_id=0, flame_model=model, landmarks=landmarks.canonical("445", st))
+        pred = FaceMeshPredictor.random_init(dtype=dtype, tune=True, cuda_id=0, flame_model=model, landmarks=landmarks.canonical("445", st))
         g = torch.Generator().manual_seed(0)
         images = torch.randint(0, 255, (batch, 256, 256, 3), dtype=torch.uint8, generator=g).cuda()
         x = torch.randn(batch, 3, 256, 256, device="cuda")
