@@ -2,7 +2,7 @@
 
 Authoring-container only (needs /root/reference; the GPU box has none). Used by
 tests/golden/make_decode_golden.py to generate the committed fixtures and by
-tests/test_oracle_vs_reference.py (auto-skipped when the reference tree is absent).
+tests/test_oracle_flame.py::test_oracle_bitwise_equals_live_reference (auto-skipped when the reference tree is absent).
 
 The reference cannot be imported as-is here: `hydra`, `smplx`,
 `pytorch_toolbelt` are not installed and `static/flame.pkl` is missing. This module registers
