@@ -25,7 +25,7 @@ import torch
 
 REF = os.environ.get("DAD3D_REFERENCE_ROOT", "/root/reference")
 BENCH = os.path.join(REF, "dad_3dheads_benchmark")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lmk68_embedding.npz")
+OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "lmk68_embedding.npz")
 
 
 def install_stubs():

@@ -10,7 +10,7 @@ import types
 import numpy as np
 
 REF = os.environ.get("DAD3D_REFERENCE_ROOT", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "projection_golden.npz")
+OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "projection_golden.npz")
 
 
 def annotation(rng, n=5023):
