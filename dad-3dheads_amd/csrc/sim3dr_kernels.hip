@@ -338,10 +338,11 @@ __global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* 
 // Two launches per batch:
 //   tri_geometry_kernel  one lane per triangle, once per image. The vertices of the image are staged in LDS
 //                        (60 KB for FLAME), so the corner coordinates are LDS gathers instead of scattered global
-//                        loads. It writes one 64-byte record per triangle -- the screen bounding box exactly as
-//                        rasterize_kernel.cpp:246-254 computes it, the pixel-independent half of get_point_weight
-//                        (TriSetup) and the corner depths -- and appends the triangle to the list of every 64x64
-//                        screen tile its box touches (LDS counters, one global atomic per block and tile).
+//                        loads. It writes one 48-byte record per on-screen triangle -- the screen bounding box exactly
+//                        as rasterize_kernel.cpp:246-254 computes it, the pixel-independent half of get_point_weight
+//                        (TriSetup less its three dot products) and the corner depths -- and appends the triangle to
+//                        the list of every 64x64 screen tile its box touches (LDS counters, one global atomic per
+//                        block and tile). With WITH_LIGHT it first lights its share of the vertices (RenderPipeline).
 //                        Its last block to finish turns the tile counters into a work queue, heaviest first; a tile
 //                        that costs more than kSplit1 (kSplit2) becomes 4 (16) items of 32x32 (16x16) pixels, so no
 //                        item is much heavier than the rest (eyes, lips and ears of a head mesh put 3000+ triangles
@@ -389,8 +390,8 @@ __device__ __forceinline__ int area_class(int area) {
 }
 
 struct RasterScratch {
-    float4* rec;        // [B][ntri][4]   TriSetup, corner depths, screen box (x0 | x1 << 16, y0 | y1 << 16; empty =
-                        //                (1,0),(1,0)) of a triangle
+    float4* rec;        // [B][ntri][3]   corner 0, edge vectors, inv, corner depths, screen box (x0 | x1 << 16,
+                        //                y0 | y1 << 16) of every on-screen triangle
     unsigned* counts;   // [2][B * ntiles]  triangles in a tile list, then the sum of their box areas inside the tile;
                         //                  zero between launches (the queue kernel resets them)
     unsigned* lists;    // [B * ntiles][ntri]   triangle | area class within the tile << 28
