@@ -83,13 +83,16 @@ class FaceMeshPredictor:
         return cls(config=load_default_config(), **kwargs)
 
     @classmethod
-    def random_init(cls, dtype: torch.dtype = torch.bfloat16, seed: int = 0, tune: bool = False, **kwargs):
+    def random_init(cls, dtype: torch.dtype = torch.bfloat16, seed: int = 0, tune: bool = False, graph: bool = False, **kwargs):
         """DAD-3DNet architecture declared in `network.py` with seeded random weights (no checkpoint offline):
         the real compute and memory footprint of the front half for throughput and plumbing tests."""
         from .config import load_default_config
-        from .network import DAD3DNet, InferenceNet
+        from .network import DAD3DNet, GraphedNet, InferenceNet
 
-        return cls(config=load_default_config(), model=InferenceNet(DAD3DNet(seed=seed), dtype, tune=tune), **kwargs)
+        net = InferenceNet(DAD3DNet(seed=seed), dtype, tune=tune)
+        device = torch.device("cuda", kwargs.get("cuda_id", 0))
+        model = GraphedNet(net.to(device)) if graph else net  # graph=True: one hipGraph per input shape
+        return cls(config=load_default_config(), model=model, **kwargs)
 
     # -- preprocess (predictor.py:86-95,195-203) ---------------------------------------------------------
     def _geometry(self, hw: Tuple[int, int]) -> Tuple[List[int], float, Tuple[int, int]]:

@@ -161,3 +161,23 @@ def test_68_landmarks_on_device_equal_host(net_predictor, static):
     assert on_dev.is_cuda and on_dev.shape == (5, 68, 3)
     assert torch.equal(on_dev.cpu(), Landmarks68(static["faces"])(verts.cpu()))
     assert seven_landmarks(on_dev).shape == (5, 7, 3)
+
+
+def test_graphed_network_equals_eager(flame_model):
+    """GraphedNet: the frozen CNN replayed from a hipGraph (one per input shape) gives the eager outputs."""
+    from dad_3dheads_amd.network import DAD3DNet, GraphedNet, InferenceNet
+
+    net = InferenceNet(DAD3DNet(seed=1), torch.bfloat16).cuda()
+    graphed = GraphedNet(net)
+    for shape in ((1, 3, 256, 256), (3, 3, 256, 256), (1, 3, 256, 256)):
+        for seed in (0, 1):
+            x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).cuda()
+            want, got = net(x), graphed(x)
+            for k in want:
+                assert torch.allclose(want[k], got[k], atol=2e-2, rtol=2e-2), k  # bf16 kernels may differ eager/captured
+    assert len(graphed._graphs) == 2
+    pred = FaceMeshPredictor.random_init(graph=True, cuda_id=0, flame_model=flame_model)
+    rng = np.random.default_rng(9)
+    for hw in ((256, 256), (300, 200), (256, 256)):
+        res = pred(rng.integers(0, 255, (hw[0], hw[1], 3), dtype=np.uint8))
+        assert res["3d_vertices"].shape == (5023, 3) and torch.isfinite(res["3d_vertices"]).all()

@@ -43,6 +43,15 @@ def main():
         out[name] = {"images_per_s_end_to_end": batch / t_all, "ms_per_batch_end_to_end": t_all * 1e3,
                      "ms_cnn_only": t_cnn * 1e3, "ms_decode_only": t_dec * 1e3,
                      "decode_share_of_batch_time": t_dec / t_all}
+    # single image, the reference's call pattern: ~200 launch-bound kernels at batch 1 -> replay them from a hipGraph
+    import numpy as np
+
+    img1 = np.random.default_rng(0).integers(0, 255, (256, 256, 3), dtype=np.uint8)
+    for name, graph in (("eager", False), ("hipgraph", True)):
+        pred = FaceMeshPredictor.random_init(dtype=torch.bfloat16, tune=True, graph=graph, cuda_id=0, flame_model=model,
+                                             landmarks=landmarks.canonical("445", st))
+        t = timed(lambda: pred(img1), 50, 10)
+        out.setdefault("single_image_ms", {})[name] = t * 1e3
     print(json.dumps(out))
 
 
