@@ -91,21 +91,34 @@ class BiFPNBlock(nn.Module):
         self.out = nn.ModuleList([SeparableBlock(ch) for _ in range(4)])  # P4, P5, P6, P7 (bottom-up order)
         self.w_td = nn.Parameter(torch.ones(2, 4))
         self.w_out = nn.Parameter(torch.ones(3, 4))
+        self.frozen = None  # (a, b) as nested lists of floats once fold_batchnorm() has frozen the block
 
-    def forward(self, levels: Sequence[Tensor]) -> List[Tensor]:
-        p3, p4, p5, p6, p7 = levels
+    def fusion_weights(self):
         a = F.relu(self.w_td)
         a = a / a.sum(0) + self.eps
         b = F.relu(self.w_out)
         b = b / b.sum(0) + self.eps
-        t6 = self.td[0](a[0, 0] * p6 + a[1, 0] * _resize_to(p7, p6))
-        t5 = self.td[1](a[0, 1] * p5 + a[1, 1] * _resize_to(t6, p5))
-        t4 = self.td[2](a[0, 2] * p4 + a[1, 2] * _resize_to(t5, p4))
-        o3 = self.td[3](a[0, 3] * p3 + a[1, 3] * _resize_to(t4, p3))
-        o4 = self.out[0](b[0, 0] * p4 + b[1, 0] * t4 + b[2, 0] * _resize_to(o3, p4))
-        o5 = self.out[1](b[0, 1] * p5 + b[1, 1] * t5 + b[2, 1] * _resize_to(o4, p5))
-        o6 = self.out[2](b[0, 2] * p6 + b[1, 2] * t6 + b[2, 2] * _resize_to(o5, p6))
-        o7 = self.out[3](b[0, 3] * p7 + b[1, 3] * p7 + b[2, 3] * _resize_to(o6, p7))
+        return a, b
+
+    def forward(self, levels: Sequence[Tensor]) -> List[Tensor]:
+        p3, p4, p5, p6, p7 = levels
+        if self.frozen is not None:  # inference: the weights are python floats, a weighted sum is two passes, not three
+            a, b = self.frozen
+            fuse2 = lambda w0, x0, w1, x1: torch.add(w0 * x0, x1, alpha=w1)  # noqa: E731
+            fuse3 = lambda w0, x0, w1, x1, w2, x2: torch.add(torch.add(w0 * x0, x1, alpha=w1), x2, alpha=w2)  # noqa: E731
+        else:
+            ta, tb = self.fusion_weights()
+            a, b = [[ta[i, j] for j in range(4)] for i in range(2)], [[tb[i, j] for j in range(4)] for i in range(3)]
+            fuse2 = lambda w0, x0, w1, x1: w0 * x0 + w1 * x1  # noqa: E731
+            fuse3 = lambda w0, x0, w1, x1, w2, x2: w0 * x0 + w1 * x1 + w2 * x2  # noqa: E731
+        t6 = self.td[0](fuse2(a[0][0], p6, a[1][0], _resize_to(p7, p6)))
+        t5 = self.td[1](fuse2(a[0][1], p5, a[1][1], _resize_to(t6, p5)))
+        t4 = self.td[2](fuse2(a[0][2], p4, a[1][2], _resize_to(t5, p4)))
+        o3 = self.td[3](fuse2(a[0][3], p3, a[1][3], _resize_to(t4, p3)))
+        o4 = self.out[0](fuse3(b[0][0], p4, b[1][0], t4, b[2][0], _resize_to(o3, p4)))
+        o5 = self.out[1](fuse3(b[0][1], p5, b[1][1], t5, b[2][1], _resize_to(o4, p5)))
+        o6 = self.out[2](fuse3(b[0][2], p6, b[1][2], t6, b[2][2], _resize_to(o5, p6)))
+        o7 = self.out[3](fuse3(b[0][3], p7, b[1][3], p7, b[2][3], _resize_to(o6, p7)))
         return [o3, o4, o5, o6, o7]
 
 
@@ -205,6 +218,15 @@ def fold_batchnorm(module: nn.Module) -> nn.Module:
     elif isinstance(module, SeparableBlock) and isinstance(module.bn, nn.BatchNorm2d):
         module.pointwise = _fold(module.pointwise, module.bn)
         module.bn = nn.Identity()
+        if isinstance(module.depthwise, nn.Conv2d) and module.depthwise.kernel_size == (1, 1) and module.depthwise.bias is None:
+            # a 1x1 depthwise convolution is a per-channel scale of the pointwise convolution's input: fold it in
+            with torch.no_grad():
+                module.pointwise.weight.mul_(module.depthwise.weight.view(1, -1, 1, 1))
+            module.depthwise = nn.Identity()
+    elif isinstance(module, BiFPNBlock):
+        with torch.no_grad():
+            a, b = module.fusion_weights()
+        module.frozen = (a.tolist(), b.tolist())
     return module
 
 
