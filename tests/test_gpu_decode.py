@@ -142,6 +142,33 @@ def test_linearity_and_determinism_at_full_size(hm):
     assert (out["proj"] - expect).abs().max() < 1e-3
 
 
+def test_config3_batch_256_matches_oracle(hm, flame_consts):
+    """BASELINE configs[2]: batch 256, the head_mesh (.obj vertices) path, every row against the oracle."""
+    params = synthetic.synthetic_params(256, seed=256)
+    v_ref = flame_ref.vertices_3d(flame_consts, torch.from_numpy(params.copy())).numpy()
+    verts = hm.vertices_3d(torch.from_numpy(params).cuda())
+    assert verts.shape == (256, 5023, 3)
+    assert np.abs(verts.cpu().numpy() - v_ref).max() < TOL_V
+
+
+def test_config4_batch_2048_on_one_gpu(hm, flame_consts):
+    """BASELINE configs[3]'s whole batch on ONE GPU (32 decode blocks per basis tile): the rows the oracle is run
+    on agree with it, rows repeated in far-apart blocks are bit-identical, and every output is finite."""
+    params = synthetic.synthetic_params(2048, seed=2048)
+    params[1024:1088] = params[:64]  # block 16 repeats block 0
+    params[2047] = params[3]         # and the very last row repeats row 3
+    dev = torch.from_numpy(params).cuda()
+    out = hm.decode(dev, to_2d=True, landmarks=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    for k in ("verts3d", "proj", "lmk_xy", "lmk_px"):
+        assert torch.equal(out[k][:64], out[k][1024:1088]) and torch.equal(out[k][3], out[k][2047])
+        assert bool(torch.isfinite(out[k].float()).all())
+    rows = np.r_[0:8, 1000:1008, 2040:2048]
+    v_ref, p_ref, _ = oracle_outputs(flame_consts, params[rows], to_2d=True)
+    assert np.abs(out["verts3d"][rows].cpu().numpy() - v_ref).max() < TOL_V
+    assert np.abs(out["proj"][rows].cpu().numpy() - p_ref).max() < TOL_PX
+
+
 def test_full_pose_config_neck_and_eyeballs(flame_model, static):
     """A constants dict that feeds neck + eyeball poses (K = 437 -> the 28-group kernel instantiation)."""
     consts = {"shape": 300, "expression": 100, "jaw": 3, "rotation": 6, "eyeballs": 6, "neck": 3, "translation": 3, "scale": 1}
