@@ -11,13 +11,16 @@ resident in HBM: prologue kernel + fused blend-shape/skinning/projection kernel 
 `FaceMeshPredictor` + `draw_3d_landmarks` derive from one params row (predictor.py:136-137,
 demo_utils.py:42-46; the reference decodes twice, this path once). BASELINE.json configs[1].
 
-`--streams S` (default 2) issues the steps round-robin on S HIP streams, each with its own fork of the decode handle
-(model constants shared in HBM) and its own params / output buffers: a serving loop with S batches of 64 in flight, which
-hides the launch gap and the start-up / epilogue tails of one launch behind the GEMM of another (+12 % with S = 2 over
-S = 1, no further gain with 3..6). Every step is still one launch over one batch of 64 and every
-step's outputs are verified after the timed region. The roofline object is about the kernel itself: its duration is
-always measured on ONE stream with back-to-back launches (`config.single_stream_ms_per_step`), which is what rocprofv3
-reports per kernel.
+Default (`--streams 1`, the contract line): every step is launched on one HIP stream; two hipEvents on that stream
+bracket the K launches of the timed region, and `roofline.achieved` = algorithmic flops per launch / (event time / K) --
+the number `rocprofv3 --kernel-trace --stats` of the same command reports as the kernel's average duration
+(profiles/r01_bench_kernel_stats.csv).
+
+`--streams S` issues the steps round-robin on S HIP streams, each with its own fork of the decode handle (model
+constants shared in HBM) and its own params / output buffers: a serving loop with S batches of 64 in flight, which
+hides the launch gap and the start-up / epilogue tails of one launch behind the GEMM of another (5.27 M img/s with
+S = 2, +12 %; no further gain with 3..6). Kernels of different streams then overlap, so the kernel
+duration for the roofline object is taken from one more pass of K launches on ONE stream.
 
 Multi-GPU: images shard over ranks (weak scaling, 64 per GPU per step, no data-path collective); the timed
 region ends with the job's single RCCL all-gather of the last step's landmarks (north_star: "RCCL/xGMI
@@ -115,7 +118,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps are issued on, round-robin")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued on, round-robin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -174,10 +177,18 @@ def main() -> None:
         step(k)
     if dist is not None:
         gather_last(max(args.warmup - 1, 0))  # RCCL communicator warm-up (untimed)
+    import ctypes as C
+
+    handle, stream = sets[0]["call"][0], sets[0]["call"][-1]
+    tot, cnt = C.c_double(), C.c_int()
     fence()
     t0 = time.perf_counter()
+    if n_streams == 1:  # two hipEvents on the launch stream bracket the K launches of the timed region itself
+        _lib.check(lib.dad3d_flame_profile_begin(handle, stream))
     for k in range(args.steps):
         step(k)
+    if n_streams == 1:
+        _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     if dist is not None:
         gather_last(args.steps - 1)
     fence()
@@ -187,18 +198,16 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant-kernel duration: the same K steps again, the run of back-to-back fused-decode launches bracketed
-    # by two hipEvents on the launch stream (one kernel per step, so elapsed / K is its average duration + gap)
-    import ctypes as C
-
-    handle, stream = sets[0]["call"][0], sets[0]["call"][-1]
-    _lib.check(lib.dad3d_flame_profile_begin(handle, stream))
-    for _ in range(args.steps):
-        st = decode(*sets[0]["call"])
-        if st:
-            _lib.check(st)
-    tot, cnt = C.c_double(), C.c_int()
-    _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
+    # dominant-kernel duration = hipEvent time of the K back-to-back launches / K (one kernel per step). With one
+    # stream the events bracketed the timed region; with several, kernels of different streams overlap and a launch's
+    # duration is no longer a property of the kernel, so the same K steps are run once more on ONE stream.
+    if n_streams > 1:
+        _lib.check(lib.dad3d_flame_profile_begin(handle, stream))
+        for _ in range(args.steps):
+            st = decode(*sets[0]["call"])
+            if st:
+                _lib.check(st)
+        _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     kern_s = tot.value / max(cnt.value, 1) * 1e-3
 
     # sanity: the timed path produced the oracle's answer (cheap spot check on rank 0, outside the timed region)

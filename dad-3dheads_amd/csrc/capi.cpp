@@ -197,7 +197,7 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
         for (int j = 0; j < kNumJoints; ++j) w8[(size_t)v * 8 + j] = w[j];
         w8[(size_t)v * 8 + 5] = ((w[0] + w[1]) + w[3]) + w[4];  // weight of the joints that cannot rotate (jaw-only mode)
     }
-    std::vector<int> head(V, -1);
+    std::vector<int> head((size_t)V * 2, -1);  // [V][2]: first landmark slot of the vertex, the slot after it
 
     dad3d_status st;
     h->c = std::make_shared<FlameConsts>();
@@ -240,9 +240,9 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->prof_launches = 0;
     dad3d_status st = DAD3D_OK;
     const size_t nv = (size_t)parent->n_verts, nl = (size_t)std::max(parent->n_lmk, 0);
-    if (hipMalloc(reinterpret_cast<void**>(&h->d_lmk_head), std::max<size_t>(nv, 1) * sizeof(int)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_lmk_head), std::max<size_t>(nv, 1) * 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_lmk_next), std::max<size_t>(nl, 1) * sizeof(int)) != hipSuccess ||
-        hipMemcpy(h->d_lmk_head, parent->d_lmk_head, nv * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy(h->d_lmk_head, parent->d_lmk_head, nv * 2 * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess ||
         (nl && hipMemcpy(h->d_lmk_next, parent->d_lmk_next, nl * sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess) ||
         (st = upload(&h->d_sync, std::vector<unsigned>(kSyncWords, 0u))) != DAD3D_OK) {
         if (st == DAD3D_OK) set_error("dad3d_flame_fork: device allocation or copy failed");
@@ -266,12 +266,15 @@ dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n
         next[s] = head[idx[s]];
         head[idx[s]] = s;
     }
+    std::vector<int> head2((size_t)h->n_verts * 2, -1);  // what the kernel stages per tile: {head, next[head]}
+    for (int v = 0; v < h->n_verts; ++v)
+        if (head[v] >= 0) head2[(size_t)v * 2] = head[v], head2[(size_t)v * 2 + 1] = next[head[v]];
     DeviceGuard guard(h->device);
     int* d_next = nullptr;
     dad3d_status st = upload(&d_next, next);
     if (st) return st;
     DAD3D_HIP_TRY(hipDeviceSynchronize());  // no decode may still be walking the old lists
-    DAD3D_HIP_TRY(hipMemcpy(h->d_lmk_head, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice));
+    DAD3D_HIP_TRY(hipMemcpy(h->d_lmk_head, head2.data(), head2.size() * sizeof(int), hipMemcpyHostToDevice));
     (void)hipFree(h->d_lmk_next);
     h->d_lmk_next = d_next;
     h->n_lmk = n;

@@ -77,7 +77,7 @@ struct DecodeArgs {
     const float* jdirs;     // [15][n_betas]  J_regressor . shapedirs
     const float* j0;        // [15]           J_regressor . v_template
     const float* weights8;  // [V][8] skinning weights w0..w4, S = w0+w1+w3+w4, 0, 0
-    const int* lmk_head;    // [V] first landmark slot of a vertex or -1
+    const int* lmk_head;    // [V][2] first landmark slot of a vertex or -1, and the slot chained after it (or -1)
     const int* lmk_next;    // [n_lmk] next slot with the same vertex or -1
     float* imgc;            // [B][kImgConsts] per-image constants: pose role -> decode role hand-off
     unsigned* sync;         // [0] arrivals (monotonic over launches)  [1] hand-off time-outs (sticky)

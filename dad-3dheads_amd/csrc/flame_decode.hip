@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     // (LDS address space spelled out: through a generic volatile pointer these become FLAT accesses that queue
     // behind the wave's outstanding global loads)
     typedef __attribute__((address_space(3))) int lds_int;
-    lds_int* part_ready = (lds_int*)(lmkh + 21);  // lmkh[0..20] = landmark heads of the 21 vertices
+    lds_int* part_ready = (lds_int*)(lmkh + 21);  // [0..20] unused since the heads moved next to the weights
     lds_int* handoff_flag = (lds_int*)(lmkh + 24);  // 0 = pending, 1 = published, 2 = timed out
     if (tid < 4) __hip_atomic_store(part_ready + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // [3] = the flag
     __syncthreads();
@@ -617,13 +617,13 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         const int trow = (wave - 4) * 16 + lane;
         const bool tail_live = lane < 16 && img0 + trow < a.batch;
         if (tail_live) pose_in = load_pose(a.params + (size_t)(img0 + trow) * P, a.lay);
-        float vc = 0.0f;
-        int lh = -1;
+        // slots 0..5 of a vertex: skinning weights; slots 6, 7: its first landmark slot and the one chained after it
+        float vc = __int_as_float(-1);
         if (ht < kTileVerts * 8) {
-            const int v = v0 + ht / 8;
-            vc = (v < a.n_verts) ? a.weights8[(size_t)v * 8 + (ht & 7)] : 0.0f;
+            const int v = v0 + ht / 8, slot = ht & 7;
+            if (v < a.n_verts) vc = slot < 6 ? a.weights8[(size_t)v * 8 + slot] : __int_as_float(a.lmk_head[(size_t)v * 2 + slot - 6]);
+            else if (slot < 6) vc = 0.0f;
         }
-        if (ht < kTileVerts && v0 + ht < a.n_verts && a.n_lmk > 0) lh = a.lmk_head[v0 + ht];
         stamp(1);
         DAD3D_WRITE_PART(0)
         publish_part(0);
@@ -660,7 +660,6 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
                             float4{tail[4 * i], tail[4 * i + 1], tail[4 * i + 2], tail[4 * i + 3]};
                 }
                 if (ht < kTileVerts * 8) vconst[ht] = vc;
-                if (ht < kTileVerts) lmkh[ht] = lh;
         }
         DAD3D_WRITE_PART(2)
         publish_part(2);
@@ -726,10 +725,10 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     const int v = v0 + j;
     const bool vlive = (g < 3) && (v < a.n_verts);
     const float4 wa = reinterpret_cast<const float4*>(vconst)[j * 2];      // w0 w1 w2 w3
-    const float4 wb = reinterpret_cast<const float4*>(vconst)[j * 2 + 1];  // w4 S . .
-    const int lhead = lmkh[j];
-    // a vertex's landmark slots do not depend on the image: fetch the (almost always empty) tail once
-    const int lnext = (lhead >= 0) ? a.lmk_next[lhead] : -1;
+    const float4 wb = reinterpret_cast<const float4*>(vconst)[j * 2 + 1];  // w4 S head next
+    // a vertex's landmark slots do not depend on the image: head and the (almost always empty) tail were staged with
+    // the weights, so the epilogue starts without a global load
+    const int lhead = __float_as_int(wb.z), lnext = __float_as_int(wb.w);
     const bool to2d = (a.flags & DAD3D_TO_2D) != 0;
     const bool zero_rot = (a.flags & DAD3D_ZERO_ROTATION) != 0;
     const float zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;

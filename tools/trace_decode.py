@@ -29,7 +29,9 @@ for _ in range(20):
     hm.decode(p, to_2d=True, landmarks_px=True)
 _lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, trace.data_ptr()))
 v3 = torch.empty((batch, 5023, 3), device="cuda"); pr = torch.empty((batch, 5023, 2), device="cuda"); lp = torch.empty((batch, 445, 2), dtype=torch.int32, device="cuda")
-_lib.check(lib.dad3d_flame_decode(hm.flame._handle, p.data_ptr(), batch, _lib.TO_2D | dbg, v3.data_ptr(), pr.data_ptr(), None, lp.data_ptr(), None))
+drop = os.environ.get("DAD3D_TRACE_DROP", "")  # diagnostics: leave outputs out ("v" = 3d_vertices, "p" = projection, "l" = landmarks)
+_lib.check(lib.dad3d_flame_decode(hm.flame._handle, p.data_ptr(), batch, _lib.TO_2D | dbg, None if "v" in drop else v3.data_ptr(),
+                                  None if "p" in drop else pr.data_ptr(), None, None if "l" in drop else lp.data_ptr(), None))
 torch.cuda.synchronize()
 _lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None))
 allrows = trace.cpu().numpy().astype(np.float64)
@@ -63,3 +65,18 @@ if pose[..., 7].max() > 0:
     print("pose second pass (warm I-cache) of joints+block: %.0f ticks" % (pose[..., 7] - pose[..., 6])[pl].mean())
 if pose[..., 9].max() > 0:
     print("  warm pass: dots %.0f, reduce+read %.0f, scalar block %.0f" % tuple((pose[..., k1] - pose[..., k0])[pl].mean() for k0, k1 in ((6, 8), (8, 9), (9, 7))))
+if os.environ.get("DAD3D_TRACE_SPREAD"):
+    # which workgroups end late? per-XCD and per-phase spread (wall clock, us after the first wave)
+    end = us(full[:, :, 13].max(axis=1)); beg = us(full[:, :, 12].min(axis=1))
+    gid = np.arange(grid); xcd = gid % 8
+    print("end by XCD (min/mean/max):", [(round(float(end[xcd == x].min()), 2), round(float(end[xcd == x].mean()), 2), round(float(end[xcd == x].max()), 2)) for x in range(8)])
+    print("start by XCD (mean):", [round(float(beg[xcd == x].mean()), 2) for x in range(8)])
+    dm = d[:, :4].mean(axis=1)  # [grid, phase]
+    for i, n in enumerate(names):
+        q = np.percentile(dm[:, i], [0, 10, 50, 90, 100])
+        print(f"  {n:26s} p0/10/50/90/100 = " + " ".join(f"{x:8.0f}" for x in q))
+    order = np.argsort(end)
+    print("earliest 8 workgroups:", [(int(g_), round(float(end[g_]), 2)) for g_ in order[:8]])
+    print("latest 8 workgroups:  ", [(int(g_), round(float(end[g_]), 2)) for g_ in order[-8:]])
+    print("corr(end, start) = %.2f; corr(end, GEMM) = %.2f; corr(end, first chunk) = %.2f; corr(end, epilogue) = %.2f" % (
+        np.corrcoef(end, beg)[0, 1], np.corrcoef(end, dm[:, 2])[0, 1], np.corrcoef(end, dm[:, 1])[0, 1], np.corrcoef(end, dm[:, 4])[0, 1]))
