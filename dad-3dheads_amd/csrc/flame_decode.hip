@@ -733,6 +733,20 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     const bool zero_rot = (a.flags & DAD3D_ZERO_ROTATION) != 0;
     const float zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
     const int pc = to2d ? 2 : 3;
+    // Output addressing: everything that is uniform over the wave (first image of the wave, first vertex of the tile)
+    // goes into ONE 64-bit scalar base per output; a lane adds a 32-bit offset (at most 9 images x the row length).
+    // 64-bit per-lane index arithmetic (v_mad_u64_u32 chains) was a fifth of the epilogue's VALU issue.
+    const int wimg = __builtin_amdgcn_readfirstlane(img0 + wave * 8);
+    float* const v3_base = a.verts3d ? a.verts3d + ((size_t)wimg * a.n_verts + v0) * 3 : nullptr;
+    float* const pj_base = a.proj ? a.proj + ((size_t)wimg * a.n_verts + v0) * pc : nullptr;
+    float* const lx_base = a.lmk_xy ? a.lmk_xy + (size_t)wimg * a.n_lmk * 2 : nullptr;
+    int* const lp_base = a.lmk_px ? a.lmk_px + (size_t)wimg * a.n_lmk * 2 : nullptr;
+    const unsigned nv = (unsigned)a.n_verts, nl = (unsigned)a.n_lmk;
+    auto put_landmark = [&](unsigned li, int slot, float ox, float oy) {
+        const unsigned off = (li * nl + (unsigned)slot) * 2u;
+        if (lx_base) *reinterpret_cast<float2*>(lx_base + off) = float2{ox, oy};
+        if (lp_base) *reinterpret_cast<int2*>(lp_base + off) = int2{(int)ox, (int)oy};  // numpy .astype(int): toward zero
+    };
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         const int li = 3 * it + g;
@@ -778,9 +792,9 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         const float rx = ra.x * px + ra.y * py + ra.z * pz;  // flame.py:226-228
         const float ry = ra.w * px + rb.x * py + rb.y * pz;
         const float rz = rb.z * px + rb.w * py + rc.x * pz;
-        const size_t bv = (size_t)b * a.n_verts + v;
-        if (a.verts3d) {
-            float* d = a.verts3d + bv * 3;
+        const unsigned lv = (unsigned)li * nv + (unsigned)j;  // (image, vertex) relative to the wave's bases
+        if (v3_base) {
+            float* d = v3_base + lv * 3u;
             d[0] = zero_rot ? px : rx;
             d[1] = zero_rot ? py : ry;
             d[2] = zero_rot ? pz : rz;
@@ -789,33 +803,16 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         const float sc = rc.y;
         const float ox = (rx * sc + rc.z + 1.0f) / 2.0f * a.image_size;
         const float oy = (ry * sc + rc.w + 1.0f) / 2.0f * a.image_size;
-        if (a.proj) {
-            float* d = a.proj + bv * pc;
+        if (pj_base) {
+            float* d = pj_base + lv * (unsigned)pc;
             d[0] = ox;
             d[1] = oy;
             if (!to2d) d[2] = zsign * ((rz * sc + 0.0f + 1.0f) / 2.0f * a.image_size);
         }
         if (lhead >= 0) {
-            const size_t l0 = ((size_t)b * a.n_lmk + lhead) * 2;
-            if (a.lmk_xy) {
-                a.lmk_xy[l0] = ox;
-                a.lmk_xy[l0 + 1] = oy;
-            }
-            if (a.lmk_px) {  // numpy .astype(int): truncation toward zero
-                a.lmk_px[l0] = (int)ox;
-                a.lmk_px[l0 + 1] = (int)oy;
-            }
-            for (int slot = lnext; slot >= 0; slot = a.lmk_next[slot]) {  // duplicate indices in the list
-                const size_t li2 = ((size_t)b * a.n_lmk + slot) * 2;
-                if (a.lmk_xy) {
-                    a.lmk_xy[li2] = ox;
-                    a.lmk_xy[li2 + 1] = oy;
-                }
-                if (a.lmk_px) {
-                    a.lmk_px[li2] = (int)ox;
-                    a.lmk_px[li2 + 1] = (int)oy;
-                }
-            }
+            put_landmark((unsigned)li, lhead, ox, oy);
+            for (int slot = lnext; slot >= 0; slot = a.lmk_next[slot])  // duplicate indices in the list
+                put_landmark((unsigned)li, slot, ox, oy);
         }
     }
     stamp(5);
