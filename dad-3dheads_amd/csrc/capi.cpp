@@ -403,6 +403,31 @@ dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_
     return DAD3D_OK;
 }
 
+dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned flags, const float* consts, const float* posed,
+                                         const float* grad_verts3d, const float* grad_proj, float* grad_posed,
+                                         float* grad_consts, void* stream) {
+    DAD3D_REQUIRE(h, "dad3d_flame_decode_backward: null handle");
+    DAD3D_REQUIRE(batch >= 0, "dad3d_flame_decode_backward: negative batch");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(consts && posed && grad_posed && grad_consts, "dad3d_flame_decode_backward: null argument");
+    DAD3D_REQUIRE(grad_verts3d || grad_proj, "dad3d_flame_decode_backward: no upstream gradient");
+    DAD3D_REQUIRE(!((flags & DAD3D_FLIP_Z) && (flags & DAD3D_TO_2D)), "DAD3D_FLIP_Z needs a 3-component projection");
+    DeviceGuard guard(h->device);
+    BackwardArgs ba{};
+    ba.weights8 = h->c->d_w8;
+    ba.consts = consts;
+    ba.posed = posed;
+    ba.g_verts3d = grad_verts3d;
+    ba.g_proj = grad_proj;
+    ba.g_posed = grad_posed;
+    ba.g_consts = grad_consts;
+    ba.batch = batch;
+    ba.n_verts = h->n_verts;
+    ba.image_size = h->image_size;
+    ba.flags = flags;
+    return launch_flame_backward(ba, static_cast<hipStream_t>(stream));
+}
+
 dad3d_status dad3d_flame_profile_begin(dad3d_flame* h, void* stream) {
     DAD3D_REQUIRE(h, "null handle");
     DeviceGuard guard(h->device);

@@ -102,6 +102,23 @@ struct DecodeArgs {
 };
 
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s);
+
+// Backward of the per-vertex half of the decode (flame_backward.hip). Per-image constants, natural joint order:
+//   [0,60) A_j rows 0..2 of the relative transforms (j = 0..4, 12 floats each)   [60,69) G row-major   [69] s   [70,72) tx ty
+constexpr int kBackwardConsts = 72;
+struct BackwardArgs {
+    const float* weights8;   // [V][8] as in DecodeArgs
+    const float* consts;     // [B][72]
+    const float* posed;      // [B,V,3] v_posed (template + blend shapes + pose correctives)
+    const float* g_verts3d;  // [B,V,3] or null
+    const float* g_proj;     // [B,V,2|3] or null
+    float* g_posed;          // [B,V,3]
+    float* g_consts;         // [B][72]
+    int batch, n_verts;
+    float image_size;
+    unsigned flags;          // DAD3D_ZERO_ROTATION | DAD3D_TO_2D | DAD3D_FLIP_Z as passed to the forward call
+};
+dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s);
 dad3d_status launch_readjust(float* params, int batch, ParamLayout lay, const float* pads_scale, float pad_left,
                              float pad_top, float scale, float img_size, hipStream_t s);
 size_t flame_decode_lds_bytes(int kgroups);

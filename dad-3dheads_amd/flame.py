@@ -4,7 +4,8 @@ Keeps the reference's names and argument meaning -- `FLAME_CONSTS`, `FlameParams
 `to_3dmm_tensor`, `FLAMELayer(consts, batch_size, flame_path)` with `.faces`, `.faces_tensor`,
 `.indices_2d`, `.flame_model`, `forward(flame_params, zero_rot)` -- but the arithmetic of
 `FLAMELayer.forward` (flame.py:182-229, i.e. `smplx.lbs.lbs` + offset + 6-DoF rotation) runs in the
-HIP library through the C ABI (include/dad3d.h). Inference only: no autograd through the HIP kernels.
+HIP library through the C ABI (include/dad3d.h). `decode()` is the raw launch; gradients flow through
+`HeadMesh.vertices_3d` / `reprojected_vertices` (autograd.py).
 """
 from __future__ import annotations
 
@@ -194,6 +195,16 @@ class FLAMELayer(torch.nn.Module):
         twin.__dict__["_handle"] = handle
         return twin
 
+    def decode_tables(self):
+        """Device tensors of the backward pass (autograd.DecodeTables), built on first use and shared with forks."""
+        t = self.__dict__.get("_decode_tables")
+        if t is None:
+            from .autograd import DecodeTables
+
+            t = DecodeTables.from_layer(self)
+            self.__dict__["_decode_tables"] = t
+        return t
+
     def set_landmarks(self, indices: Sequence[int]) -> None:
         idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int64))
         _lib.check(self._lib.dad3d_flame_set_landmarks(self._handle, idx.ctypes.data, int(idx.size)))
@@ -211,7 +222,8 @@ class FLAMELayer(torch.nn.Module):
         if params.shape[1] != self.n_params:
             raise ValueError(f"expected {self.n_params} params per row, got {params.shape[1]}")
         if params.requires_grad and torch.is_grad_enabled():
-            raise RuntimeError("the HIP decode is inference-only (no autograd); call under torch.no_grad()")
+            raise RuntimeError("FLAMELayer.decode is the raw launch (no grad_fn); differentiate through "
+                               "HeadMesh.vertices_3d / reprojected_vertices or autograd.decode_with_grad")
         if params.device != self.torch_device or params.dtype != torch.float32 or not params.is_contiguous():
             raise ValueError("params must be a contiguous float32 tensor on " + str(self.torch_device))
         b, v = params.shape[0], self.n_verts
@@ -243,6 +255,10 @@ class FLAMELayer(torch.nn.Module):
             [flame_params.shape, flame_params.expression, jaw, flame_params.rotation, flame_params.eyeballs,
              flame_params.neck, flame_params.translation, flame_params.scale], dim=-1)
         src = packed.device
+        if torch.is_grad_enabled() and packed.requires_grad:  # training callers: same launch, grad_fn attached
+            from .autograd import decode_with_grad
+
+            return decode_with_grad(self, packed, verts3d=True, proj=False, zero_rot=zero_rot)[0]
         with torch.no_grad():
             dev_params = packed.detach().to(self.torch_device, torch.float32).contiguous()
             verts = self.decode(dev_params, verts3d=True, zero_rot=zero_rot)["verts3d"]

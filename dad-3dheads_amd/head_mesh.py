@@ -7,6 +7,10 @@ passes) is staged through the GPU and returned as a CPU tensor; a CUDA tensor ne
 
 `decode()` is the MI355X-native entry: ONE launch returns `vertices_3d`, the projection and the gathered
 landmarks, where the reference runs two full decodes (predictor.py:136-137).
+
+Training callers (`losses/vertices_3d_loss.py:41`, `losses/reprojection_loss.py:33`) pass a tensor that requires grad:
+`vertices_3d` / `reprojected_vertices` then go through `autograd.decode_with_grad` (same forward launch, backward in
+the library + two rocBLAS GEMMs) and the result carries a grad_fn like the reference's.
 """
 from __future__ import annotations
 
@@ -16,6 +20,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from .autograd import decode_with_grad
 from .flame import FLAME_CONSTS, FLAMELayer, FlameParams
 
 
@@ -38,20 +43,32 @@ class HeadMesh(nn.Module):
     def _stage(self, params_3dmm: Tensor) -> Tensor:
         if params_3dmm.ndim != 2:
             raise AssertionError("tensor_3dmm.ndim == 2 expected")  # flame.py:46
-        if params_3dmm.requires_grad and torch.is_grad_enabled():
-            raise RuntimeError("the HIP decode is inference-only (no autograd); call under torch.no_grad()")
         dev = self.flame.torch_device
         if params_3dmm.device == dev and params_3dmm.dtype == torch.float32 and params_3dmm.is_contiguous():
             return params_3dmm
         return params_3dmm.detach().to(dev, torch.float32).contiguous()
 
+    @staticmethod
+    def _needs_grad(params_3dmm: Tensor) -> bool:
+        return torch.is_grad_enabled() and params_3dmm.requires_grad
+
     def vertices_3d(self, params_3dmm: Tensor, zero_rotation: bool = False) -> Tensor:
+        if self._needs_grad(params_3dmm):
+            if params_3dmm.ndim != 2:
+                raise AssertionError("tensor_3dmm.ndim == 2 expected")  # flame.py:46
+            return decode_with_grad(self.flame, params_3dmm, verts3d=True, proj=False, zero_rot=zero_rotation)[0]
         staged = self._stage(params_3dmm)
         out = self.flame.decode(staged, verts3d=True, zero_rot=zero_rotation)["verts3d"]
         return out.to(params_3dmm.device)
 
     def reprojected_vertices(self, params_3dmm: Tensor, to_2d: bool = True) -> Tensor:
         """Returns [B, N, C] (C = 2 or 3) and sets translation z := 0 in `params_3dmm`, like the reference."""
+        if self._needs_grad(params_3dmm):
+            if params_3dmm.ndim != 2:
+                raise AssertionError("tensor_3dmm.ndim == 2 expected")  # flame.py:46
+            # head_mesh.py:41, tracked by autograd exactly as in the reference (a leaf that requires grad raises there too)
+            self.flame_params(params_3dmm).translation[..., 2] = 0.0
+            return decode_with_grad(self.flame, params_3dmm, verts3d=False, proj=True, to_2d=to_2d)[1]
         staged = self._stage(params_3dmm)
         out = self.flame.decode(staged, proj=True, to_2d=to_2d, mutate=True)["proj"]
         if staged is not params_3dmm:  # replay the in-place side effect on the caller's tensor

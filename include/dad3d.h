@@ -104,6 +104,23 @@ int dad3d_flame_num_landmarks(const dad3d_flame* h);
 dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                 float* lmk_xy, int32_t* lmk_px, void* stream);
 
+/* Vertex half of the BACKWARD pass of dad3d_flame_decode, for the reference's training callers that differentiate
+ * through HeadMesh (model_training/losses/vertices_3d_loss.py:41 `vertices_3d(..., zero_rotation=True)`,
+ * reprojection_loss.py:33 `reprojected_vertices(..., to_2d=True)`; the reference gets these gradients from torch
+ * autograd over flame.py:182-229 + smplx.lbs.lbs). All pointers are DEVICE pointers; `flags` as in the forward call.
+ *   consts       [B,72]  per-image constants of the forward pass: rows 0..2 of the five relative joint transforms A_j
+ *                        (smplx batch_rigid_transform, natural joint order, 12 floats each), the 6-DoF rotation matrix
+ *                        (9, row-major), s = clamp(scale + 1, 1e-8), tx, ty
+ *   posed        [B,V,3] v_posed = template + blend shapes + pose correctives (smplx lbs, before skinning)
+ *   grad_verts3d [B,V,3] dL/d(verts3d) or NULL      grad_proj [B,V,2|3] dL/d(proj) or NULL (at least one given)
+ *   grad_posed   [B,V,3] OUT: dL/d(v_posed) -- multiply by the blend-shape basis transposed for dL/d(betas, pose feature)
+ *   grad_consts  [B,72]  OUT: dL/d(consts), summed over the vertices (deterministic: one workgroup per image)
+ * The constants are small differentiable functions of (jaw/neck/eye pose, joints(betas), rot6d, scale, translation);
+ * the host mirror (dad_3dheads_amd/autograd.py) takes their derivatives and runs the two library GEMMs. */
+dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned flags, const float* consts, const float* posed,
+                                         const float* grad_verts3d, const float* grad_proj, float* grad_posed,
+                                         float* grad_consts, void* stream);
+
 /* Same, HOST buffers in and out (synchronous; PCIe-inclusive convenience for non-HIP callers). */
 dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
                                      float* proj, float* lmk_xy, int32_t* lmk_px);

@@ -1,0 +1,134 @@
+"""GPU: gradients through `HeadMesh.vertices_3d` / `reprojected_vertices` (HIP forward, HIP + rocBLAS backward) against
+torch autograd over the CPU oracle -- the way the reference's own losses obtain them (vertices_3d_loss.py:41,
+reprojection_loss.py:33). Tolerance: 2e-4 of the largest gradient entry (fp32 sums over 15069 terms in two different
+orders); the forward values keep the decode's tolerances."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from dad_3dheads_amd import _lib, landmarks, synthetic
+from dad_3dheads_amd.flame import FLAME_CONSTS
+from dad_3dheads_amd.head_mesh import HeadMesh
+from dad_3dheads_amd.losses import ReprojectionLoss, Vertices3DLoss, normalize_to_cube
+from oracle import flame_ref
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def hm(flame_model, static):
+    return HeadMesh(flame_model=flame_model, landmarks=landmarks.canonical("445", static), static=static, device=0)
+
+
+def close(g, g_ref):
+    g, g_ref = g.detach().cpu(), g_ref.detach().cpu()
+    return float((g - g_ref).abs().max()) <= RTOL * float(g_ref.abs().max())
+
+
+@pytest.mark.parametrize("batch,zero_rot", [(3, True), (3, False), (70, True)])
+def test_vertices_3d_gradient_matches_oracle_autograd(hm, flame_consts, batch, zero_rot):
+    params = torch.from_numpy(synthetic.synthetic_params(batch, seed=300 + batch))
+    w = torch.randn((batch, 5023, 3), generator=torch.Generator().manual_seed(1))
+    p_ref = params.clone().requires_grad_(True)
+    (flame_ref.vertices_3d(flame_consts, p_ref, zero_rotation=zero_rot) * w).sum().backward()
+
+    p = params.clone().cuda().requires_grad_(True)
+    v = hm.vertices_3d(p, zero_rotation=zero_rot)
+    assert v.requires_grad and v.device == p.device and v.shape == (batch, 5023, 3)
+    with torch.no_grad():
+        assert torch.equal(v, hm.vertices_3d(p.detach(), zero_rotation=zero_rot))  # same launch as the inference path
+    (v * w.cuda()).sum().backward()
+    assert close(p.grad, p_ref.grad)
+    assert float(p.grad[:, 409:412].abs().max()) == 0.0 and float(p.grad[:, 412].abs().max()) == 0.0  # t, s unused here
+
+
+@pytest.mark.parametrize("to_2d", [True, False])
+def test_reprojection_gradient_and_in_place_side_effect(hm, flame_consts, to_2d):
+    params = torch.from_numpy(synthetic.synthetic_params(5, seed=41))
+    w = torch.randn((5, 5023, 2 if to_2d else 3), generator=torch.Generator().manual_seed(2))
+    p_ref = params.clone().requires_grad_(True)
+    q_ref = p_ref * 1.0  # the network output of the reference's training loop: a non-leaf the method writes into
+    (flame_ref.reprojected_vertices(flame_consts, q_ref, to_2d=to_2d) * w).sum().backward()
+
+    p = params.clone().cuda().requires_grad_(True)
+    q = p * 1.0
+    proj = hm.reprojected_vertices(q, to_2d=to_2d)
+    assert float(q.detach()[:, 411].abs().max()) == 0.0  # head_mesh.py:41
+    (proj * w.cuda()).sum().backward()
+    assert close(p.grad, p_ref.grad)
+    assert float(p.grad[:, 411].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):  # a leaf that requires grad cannot be written in place -- in the reference either
+        hm.reprojected_vertices(params.clone().cuda().requires_grad_(True))
+
+
+def test_cpu_tensors_round_trip_and_backward_is_reproducible(hm, flame_consts):
+    params = torch.from_numpy(synthetic.synthetic_params(4, seed=9))
+    w = torch.randn((4, 5023, 3), generator=torch.Generator().manual_seed(3))
+    grads = []
+    for _ in range(2):
+        p = params.clone().requires_grad_(True)  # CPU leaf, like predictor-side callers: staged through the GPU
+        v = hm.vertices_3d(p)
+        assert v.device.type == "cpu"
+        (v * w).sum().backward()
+        grads.append(p.grad.clone())
+    assert torch.equal(grads[0], grads[1])  # one workgroup per image, no atomics
+    p_ref = params.clone().requires_grad_(True)
+    (flame_ref.vertices_3d(flame_consts, p_ref) * w).sum().backward()
+    assert close(grads[0], p_ref.grad)
+    # FLAMELayer.forward (losses / pncc call style) carries the same graph
+    p = params.clone().cuda().requires_grad_(True)
+    (hm.flame.forward(hm.flame_params(p), zero_rot=True) * w.cuda()).sum().backward()
+    p_ref = params.clone().requires_grad_(True)
+    (flame_ref.vertices_3d(flame_consts, p_ref, zero_rotation=True) * w).sum().backward()
+    assert close(p.grad, p_ref.grad)
+
+
+def test_reference_losses_values_and_gradients(flame_model, flame_consts, static):
+    regions = ([1.0, 0.5, 2.0], [np.arange(0, 5023, 7), landmarks.canonical("445", static)[:200], np.arange(3000, 3600)])
+    kw = dict(flame_model=flame_model, static=static, device=0)
+    batch = 6
+    params = torch.from_numpy(synthetic.synthetic_params(batch, seed=11))
+    tgt3d = flame_ref.vertices_3d(flame_consts, torch.from_numpy(synthetic.synthetic_params(batch, seed=12)), zero_rotation=True)
+    tgt2d = flame_ref.reprojected_vertices(flame_consts, torch.from_numpy(synthetic.synthetic_params(batch, seed=13)))
+
+    for crit in ("l1", "l2", "smooth_l1"):
+        fn = {"l1": torch.nn.L1Loss, "l2": torch.nn.MSELoss, "smooth_l1": torch.nn.SmoothL1Loss}[crit]()
+        # Vertices3DLoss (vertices_3d_loss.py:31-49)
+        loss = Vertices3DLoss(crit, batch, FLAME_CONSTS, regions, **kw)
+        p = params.clone().cuda().requires_grad_(True)
+        val = loss(p * 1.0, tgt3d.cuda())
+        val.backward()
+        p_ref = params.clone().requires_grad_(True)
+        v_ref = flame_ref.vertices_3d(flame_consts, p_ref * 1.0, zero_rotation=True)
+        ref = torch.stack([fn(normalize_to_cube(v_ref[:, i]), normalize_to_cube(tgt3d[:, i])) * w for w, i in zip(*regions)]).sum()
+        ref.backward()
+        assert abs(float(val) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+        assert close(p.grad, p_ref.grad)
+        # ReprojectionLoss (reprojection_loss.py:22-46), list target form
+        loss = ReprojectionLoss(crit, batch, FLAME_CONSTS, 256, regions, **kw)
+        p = params.clone().cuda().requires_grad_(True)
+        val = loss(p * 1.0, [tgt2d.cuda()])
+        val.backward()
+        p_ref = params.clone().requires_grad_(True)
+        pr_ref = flame_ref.reprojected_vertices(flame_consts, p_ref * 1.0)
+        ref = torch.stack([fn(pr_ref[:, i], tgt2d[:, i]) * w for w, i in zip(*regions)]).sum()
+        ref.backward()
+        assert abs(float(val) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref)))
+        assert close(p.grad, p_ref.grad)
+    with pytest.raises(ValueError, match="Unsupported discrepancy loss type"):
+        Vertices3DLoss("huber", batch, FLAME_CONSTS, regions, **kw)
+
+
+def test_c_abi_backward_argument_errors(hm):
+    lib = _lib.load()
+    buf = torch.zeros((1, 5023, 3), device="cuda")
+    c72 = torch.zeros((1, 72), device="cuda")
+    h = hm.flame._handle
+    assert lib.dad3d_flame_decode_backward(h, 0, 0, None, None, None, None, None, None, None) == 0  # empty batch
+    st = lib.dad3d_flame_decode_backward(h, 1, 0, c72.data_ptr(), buf.data_ptr(), None, None, buf.data_ptr(), c72.data_ptr(), None)
+    assert st != 0 and b"no upstream gradient" in lib.dad3d_last_error()
+    st = lib.dad3d_flame_decode_backward(None, 1, 0, c72.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, buf.data_ptr(), c72.data_ptr(), None)
+    assert st != 0
