@@ -73,6 +73,9 @@ SIGNATURES = {
     "dad3d_flame_num_landmarks": (_I, [_P]),
     "dad3d_flame_decode": (_I, [_P, _P, _I, _U, _P, _P, _P, _P, _P]),
     "dad3d_flame_decode_backward": (_I, [_P, _I, _U, _P, _P, _P, _P, _P, _P, _P]),
+    "dad3d_flame_num_chain_inputs": (_I, [_P]),
+    "dad3d_flame_pose_chain": (_I, [_P, _P, _I, _P, _P, _P]),
+    "dad3d_flame_pose_chain_backward": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "dad3d_flame_decode_host": (_I, [_P, _P, _I, _U, _P, _P, _P, _P]),
     "dad3d_flame_readjust_params": (_I, [_P, _P, _I, _P, _F, _F, _F, _P]),
     "dad3d_flame_profile_begin": (_I, [_P, _P]),

@@ -9,8 +9,12 @@ decode (`dad3d_flame_decode`) and the backward pass is split where the sizes spl
 * the two contractions with the blend-shape basis are plain library GEMMs (rocBLAS through `torch.matmul`):
   v_posed = template + [betas | pose feature] @ basis, and dL/d[betas | pose feature] = dL/d(v_posed) @ basis^T;
 * the 72 per-image constants (joint transforms, 6-DoF rotation, scale, translation) are a few hundred flops per image
-  of Rodrigues / kinematic chain / Gram-Schmidt: `pose_chain` below writes them with torch ops on [B, small] device
-  tensors and torch differentiates them.
+  of Rodrigues / kinematic chain / Gram-Schmidt: `dad3d_flame_pose_chain` evaluates them and
+  `dad3d_flame_pose_chain_backward` differentiates them with dual numbers over the same device code (one launch each
+  instead of the ~300 small kernels of a torch graph). `pose_chain` below states the same chain with torch ops; the
+  tests use it (and torch's autograd over it) to check the two kernels, and on CPU to pin the layout against the oracle.
+
+A backward pass is five launches: chain, GEMM, per-vertex kernel, GEMM, chain VJP.
 
 Formulas restated from the published smplx algorithm (`lbs.py`: batch_rodrigues, batch_rigid_transform) and
 `model_training/model/utils.py:92-101` (rot_mat_from_6dof); checked against the oracle's autograd in the tests.
@@ -156,21 +160,23 @@ class _Decode(torch.autograd.Function):
         g_pj = on_dev(g_pj, 2 if ctx.flags & _lib.TO_2D else 3)
         if g_v3 is None and g_pj is None:
             return None, None, None, None, None, None
-        with torch.enable_grad():
-            p = staged.detach().requires_grad_(True)
-            chain = pose_chain(tables, layer.flame_constants, p)
+        lib, handle = layer._lib, layer._handle
+        stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.no_grad():
-            posed = torch.addmm(tables.template, chain["inputs"], tables.basis)  # [B,3V] = v_posed, library GEMM
-            consts = chain["consts"].detach().contiguous()
+            inputs = torch.empty((b, tables.basis.shape[0]), dtype=torch.float32, device=dev)
+            consts = torch.empty((b, N_CONSTS), dtype=torch.float32, device=dev)
+            _lib.check(lib.dad3d_flame_pose_chain(handle, staged.data_ptr(), b, inputs.data_ptr(), consts.data_ptr(), stream))
+            posed = torch.addmm(tables.template, inputs, tables.basis)  # [B,3V] = v_posed, library GEMM
             g_posed = torch.empty_like(posed)
-            g_consts = torch.empty((b, N_CONSTS), dtype=torch.float32, device=dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(layer._lib.dad3d_flame_decode_backward(
-                layer._handle, b, ctx.flags, consts.data_ptr(), posed.data_ptr(),
+            g_consts = torch.empty_like(consts)
+            _lib.check(lib.dad3d_flame_decode_backward(
+                handle, b, ctx.flags, consts.data_ptr(), posed.data_ptr(),
                 g_v3.data_ptr() if g_v3 is not None else None, g_pj.data_ptr() if g_pj is not None else None,
                 g_posed.data_ptr(), g_consts.data_ptr(), stream))
             g_inputs = g_posed @ tables.basis.T  # [B,436], library GEMM
-        (g_params,) = torch.autograd.grad([chain["inputs"], chain["consts"]], [p], [g_inputs, g_consts])
+            g_params = torch.empty_like(staged)
+            _lib.check(lib.dad3d_flame_pose_chain_backward(handle, staged.data_ptr(), b, g_inputs.data_ptr(),
+                                                           g_consts.data_ptr(), g_params.data_ptr(), stream))
         return g_params.to(ctx.src_device), None, None, None, None, None
 
 

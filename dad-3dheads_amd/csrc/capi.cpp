@@ -428,6 +428,45 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
     return launch_flame_backward(ba, static_cast<hipStream_t>(stream));
 }
 
+static ChainArgs chain_args(const dad3d_flame* h, const float* params, int batch) {
+    ChainArgs ca{};
+    ca.params = params;
+    ca.jdirs = h->c->d_jdirs;
+    ca.j0 = h->c->d_j0;
+    ca.lay = h->lay;
+    std::copy(h->parents, h->parents + kNumJoints, ca.parents);
+    ca.batch = batch;
+    ca.n_betas = h->n_betas;
+    ca.max_shape = h->max_shape;
+    return ca;
+}
+
+dad3d_status dad3d_flame_pose_chain(dad3d_flame* h, const float* params, int batch, float* inputs, float* consts, void* stream) {
+    DAD3D_REQUIRE(h && batch >= 0, "dad3d_flame_pose_chain: bad argument");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(params && inputs && consts, "dad3d_flame_pose_chain: null argument");
+    DeviceGuard guard(h->device);
+    ChainArgs ca = chain_args(h, params, batch);
+    ca.inputs = inputs;
+    ca.consts = consts;
+    return launch_pose_chain(ca, false, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_flame_pose_chain_backward(dad3d_flame* h, const float* params, int batch, const float* grad_inputs,
+                                             const float* grad_consts, float* grad_params, void* stream) {
+    DAD3D_REQUIRE(h && batch >= 0, "dad3d_flame_pose_chain_backward: bad argument");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(params && grad_inputs && grad_consts && grad_params, "dad3d_flame_pose_chain_backward: null argument");
+    DeviceGuard guard(h->device);
+    ChainArgs ca = chain_args(h, params, batch);
+    ca.g_inputs = grad_inputs;
+    ca.g_consts = grad_consts;
+    ca.g_params = grad_params;
+    return launch_pose_chain(ca, true, static_cast<hipStream_t>(stream));
+}
+
+int dad3d_flame_num_chain_inputs(const dad3d_flame* h) { return h ? h->n_betas + 36 : -1; }
+
 dad3d_status dad3d_flame_profile_begin(dad3d_flame* h, void* stream) {
     DAD3D_REQUIRE(h, "null handle");
     DeviceGuard guard(h->device);

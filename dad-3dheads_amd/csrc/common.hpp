@@ -119,6 +119,22 @@ struct BackwardArgs {
     unsigned flags;          // DAD3D_ZERO_ROTATION | DAD3D_TO_2D | DAD3D_FLIP_Z as passed to the forward call
 };
 dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s);
+
+// Per-image chain (flame_backward.hip): forward writes `inputs` and `consts`; vjp reads g_inputs / g_consts, writes g_params.
+struct ChainArgs {
+    const float* params;    // [B,P]
+    const float* jdirs;     // [15][n_betas]
+    const float* j0;        // [15]
+    float* inputs;          // [B][n_betas + 36]  betas | pose feature      (forward)
+    float* consts;          // [B][72]                                      (forward)
+    const float* g_inputs;  // [B][n_betas + 36]                            (vjp)
+    const float* g_consts;  // [B][72]                                      (vjp)
+    float* g_params;        // [B,P], every entry written                   (vjp)
+    ParamLayout lay;
+    int parents[kNumJoints];
+    int batch, n_betas, max_shape;
+};
+dad3d_status launch_pose_chain(const ChainArgs& a, bool vjp, hipStream_t s);
 dad3d_status launch_readjust(float* params, int batch, ParamLayout lay, const float* pads_scale, float pad_left,
                              float pad_top, float scale, float img_size, hipStream_t s);
 size_t flame_decode_lds_bytes(int kgroups);

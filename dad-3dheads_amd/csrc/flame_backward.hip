@@ -121,7 +121,274 @@ __global__ __launch_bounds__(kBwdThreads) void flame_backward_kernel(BackwardArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Per-image half: the chain (pose, joints, rot6d, scale, translation) -> (72 constants, 36 pose features), forward and
+// vector-Jacobian product.
+//
+// The chain is a few hundred flops of Rodrigues / kinematic tree / Gram-Schmidt per image with 36 scalar inputs that
+// carry a gradient (12 pose components, 6 rot6d, scale, tx, ty, 15 joint coordinates) and 108 outputs. It is written
+// once, generic in the scalar type; the backward pass instantiates it with dual numbers (value, directional
+// derivative) and runs it 36 times per image -- lane d of the image's wave seeds input d -- so the derivative code IS
+// the forward code and cannot drift from it. The gradient of a lane is sum_i d(out_i) * g_i, accumulated as the
+// outputs are produced. The joint coordinates continue to the betas through J = J0 + Jdirs . betas.
+// ------------------------------------------------------------------------------------------------------------------
+struct Dual {
+    float v, d;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, float b) { return {a.v - b, a.d}; }
+__device__ __forceinline__ Dual operator-(float a, Dual b) { return {a - b.v, -b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+    const float q = a.v / b.v;
+    return {q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ float t_sin(float a) { return sinf(a); }
+__device__ __forceinline__ float t_cos(float a) { return cosf(a); }
+__device__ __forceinline__ float t_floor_at(float a, float lo) { return fmaxf(a, lo); }
+__device__ __forceinline__ Dual t_sqrt(Dual a) {
+    const float r = sqrtf(a.v);
+    return {r, a.d / (2.0f * r)};
+}
+__device__ __forceinline__ Dual t_sin(Dual a) { return {sinf(a.v), cosf(a.v) * a.d}; }
+__device__ __forceinline__ Dual t_cos(Dual a) { return {cosf(a.v), -sinf(a.v) * a.d}; }
+__device__ __forceinline__ Dual t_floor_at(Dual a, float lo) { return a.v >= lo ? a : Dual{lo, 0.0f}; }  // clamp(min=)
+template <typename T>
+__device__ __forceinline__ T t_const(float c);
+template <>
+__device__ __forceinline__ float t_const<float>(float c) { return c; }
+template <>
+__device__ __forceinline__ Dual t_const<Dual>(float c) { return {c, 0.0f}; }
+
+template <typename T>
+__device__ __forceinline__ void t_identity(T R[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = t_const<T>((i % 4 == 0) ? 1.0f : 0.0f);
+}
+
+// smplx.lbs.batch_rodrigues: angle = ||r + 1e-8||, axis = r / angle, R = I + sin K + (1 - cos) K K
+template <typename T>
+__device__ __forceinline__ void t_rodrigues(const T r[3], T R[9]) {
+    const T ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
+    const T angle = t_sqrt(ex * ex + ey * ey + ez * ez);
+    const T x = r[0] / angle, y = r[1] / angle, z = r[2] / angle;
+    const T sn = t_sin(angle), c1 = 1.0f - t_cos(angle);
+    const T o = t_const<T>(0.0f);
+    const T K[9] = {o, -z, y, z, o, -x, -y, x, o};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const T kk = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+            R[i * 3 + j] = ((i == j) ? 1.0f : 0.0f) + (sn * K[i * 3 + j] + c1 * kk);
+        }
+}
+
+template <typename T>
+__device__ __forceinline__ void t_normalize(T v[3]) {  // F.normalize(eps = 1e-12)
+    const T n = t_floor_at(t_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    v[0] = v[0] / n, v[1] = v[1] / n, v[2] = v[2] / n;
+}
+
+// Output numbering: [0,60) A_j rows 0..2 (natural joint order), [60,69) G row-major, 69 s, 70 tx, 71 ty,
+// [72,108) pose feature (R_j - I, j = 1..4) = columns n_betas.. of the blend-shape GEMM's A operand.
+constexpr int kChainOutputs = kBackwardConsts + 36;
+constexpr int kChainInputs = 36;  // 12 pose | 6 rot6d | scale | tx ty | 15 joint coordinates
+
+template <typename T, typename Emit>
+__device__ __forceinline__ void pose_chain_t(const ParamLayout& lay, const int* parents, const T pose[12], const T J[15],
+                                            const T rot6[6], T scale, T tx, T ty, Emit&& emit) {
+    T R[kNumJoints][9];
+    t_identity(R[0]);  // the global rotation of full_pose stays zero (flame.py:206)
+    if (lay.neck_n == 3) t_rodrigues(pose, R[1]); else t_identity(R[1]);
+    if (lay.jaw_n == 3) t_rodrigues(pose + 3, R[2]); else t_identity(R[2]);
+    if (lay.eye_n == 6) {
+        t_rodrigues(pose + 6, R[3]);
+        t_rodrigues(pose + 9, R[4]);
+    } else {
+        t_identity(R[3]);
+        t_identity(R[4]);
+    }
+#pragma unroll
+    for (int j = 1; j < kNumJoints; ++j)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) emit(kBackwardConsts + (j - 1) * 9 + i, R[j][i] - ((i % 4 == 0) ? 1.0f : 0.0f));
+    // smplx batch_rigid_transform: world_j = world_parent . [R_j | J_j - J_parent]; A_j = world_j - [0 | world_j . J_j]
+    T WR[kNumJoints][9], Wt[kNumJoints][3];
+#pragma unroll
+    for (int j = 0; j < kNumJoints; ++j) {
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) WR[0][i] = R[0][i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Wt[0][c] = J[c];
+        } else {
+            T PR[9], Pt[3], Jp[3];  // parent < j: selected without dynamic register indexing
+#pragma unroll
+            for (int i = 0; i < 9; ++i) PR[i] = t_const<T>(0.0f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Pt[c] = Jp[c] = t_const<T>(0.0f);
+#pragma unroll
+            for (int q = 0; q < kNumJoints; ++q)
+                if (q < j && q == parents[j]) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) PR[i] = WR[q][i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Pt[c] = Wt[q][c], Jp[c] = J[q * 3 + c];
+                }
+            const T rel[3] = {J[j * 3] - Jp[0], J[j * 3 + 1] - Jp[1], J[j * 3 + 2] - Jp[2]};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    WR[j][r * 3 + c] = PR[r * 3] * R[j][c] + PR[r * 3 + 1] * R[j][3 + c] + PR[r * 3 + 2] * R[j][6 + c];
+                Wt[j][r] = PR[r * 3] * rel[0] + PR[r * 3 + 1] * rel[1] + PR[r * 3 + 2] * rel[2] + Pt[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) emit(j * 12 + r * 4 + c, WR[j][r * 3 + c]);
+            emit(j * 12 + r * 4 + 3,
+                 Wt[j][r] - (WR[j][r * 3] * J[j * 3] + WR[j][r * 3 + 1] * J[j * 3 + 1] + WR[j][r * 3 + 2] * J[j * 3 + 2]));
+        }
+    }
+    // rot_mat_from_6dof (model/utils.py:92-101): columns b1, b2, b3
+    T b1[3] = {rot6[0], rot6[1], rot6[2]};
+    t_normalize(b1);
+    T b3[3] = {b1[1] * rot6[5] - b1[2] * rot6[4], b1[2] * rot6[3] - b1[0] * rot6[5], b1[0] * rot6[4] - b1[1] * rot6[3]};
+    t_normalize(b3);
+    const T b2[3] = {-(b1[1] * b3[2] - b1[2] * b3[1]), -(b1[2] * b3[0] - b1[0] * b3[2]), -(b1[0] * b3[1] - b1[1] * b3[0])};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) emit(60 + r * 3, b1[r]), emit(60 + r * 3 + 1, b2[r]), emit(60 + r * 3 + 2, b3[r]);
+    emit(69, t_floor_at(scale + 1.0f, 1e-8f));  // head_mesh.py:39
+    emit(70, tx);
+    emit(71, ty);  // translation z := 0 (head_mesh.py:41): no output depends on it
+}
+
+__device__ __forceinline__ float chain_beta(const ChainArgs& a, const float* p, int l) {  // flame.py:192-200
+    if (l < a.max_shape) return (l < a.lay.shape_n) ? p[a.lay.shape_off + l] : 0.0f;
+    return (l - a.max_shape < a.lay.expr_n) ? p[a.lay.expr_off + l - a.max_shape] : 0.0f;
+}
+
+// One wave per image. VJP = false: writes inputs [B][n_betas+36] and consts [B][72]. VJP = true: writes g_params [B][P].
+template <bool VJP>
+__global__ __launch_bounds__(64) void pose_chain_kernel(ChainArgs a) {
+    __shared__ float g_out[kChainOutputs];
+    __shared__ float g_joint[3 * kNumJoints];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* p = a.params + (size_t)b * a.lay.n_params;
+    const int n_in = a.n_betas + 36;
+    constexpr int kPasses = 7;  // 448 >= 400 betas
+    float be[kPasses], jacc[3 * kNumJoints];
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+        const int l = lane + 64 * k;
+        be[k] = l < a.n_betas ? chain_beta(a, p, l) : 0.0f;
+        if (l < a.n_betas) {
+#pragma unroll
+            for (int o = 0; o < 3 * kNumJoints; ++o) jacc[o] += a.jdirs[(size_t)o * a.n_betas + l] * be[k];
+        }
+    }
+    float J[3 * kNumJoints];
+#pragma unroll
+    for (int o = 0; o < 3 * kNumJoints; ++o) J[o] = a.j0[o] + wave_sum64(jacc[o]);
+    float pose[12], rot6[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pose[c] = (a.lay.neck_n == 3) ? p[a.lay.neck_off + c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pose[3 + c] = (a.lay.jaw_n == 3) ? p[a.lay.jaw_off + c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pose[6 + c] = (a.lay.eye_n == 6) ? p[a.lay.eye_off + c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rot6[c] = p[a.lay.rot_off + c];
+    const float scale = p[a.lay.scale_off], tx = p[a.lay.trans_off], ty = p[a.lay.trans_off + 1];
+
+    if (!VJP) {
+#pragma unroll
+        for (int k = 0; k < kPasses; ++k) {
+            const int l = lane + 64 * k;
+            if (l < a.n_betas) a.inputs[(size_t)b * n_in + l] = be[k];
+        }
+        if (lane == 0) {
+            float* c_out = a.consts + (size_t)b * kBackwardConsts;
+            float* f_out = a.inputs + (size_t)b * n_in + a.n_betas;
+            pose_chain_t<float>(a.lay, a.parents, pose, J, rot6, scale, tx, ty, [&](int i, float val) {
+                if (i < kBackwardConsts) c_out[i] = val; else f_out[i - kBackwardConsts] = val;
+            });
+        }
+        return;
+    }
+    // ---- vector-Jacobian product --------------------------------------------------------------------------------
+    for (int i = lane; i < kChainOutputs; i += 64)
+        g_out[i] = i < kBackwardConsts ? a.g_consts[(size_t)b * kBackwardConsts + i]
+                                       : a.g_inputs[(size_t)b * n_in + a.n_betas + i - kBackwardConsts];
+    __syncthreads();
+    float* gp = a.g_params + (size_t)b * a.lay.n_params;
+    if (lane < kChainInputs) {
+        Dual dpose[12], dJ[3 * kNumJoints], drot[6];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) dpose[c] = Dual{pose[c], lane == c ? 1.0f : 0.0f};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) drot[c] = Dual{rot6[c], lane == 12 + c ? 1.0f : 0.0f};
+        const Dual dscale{scale, lane == 18 ? 1.0f : 0.0f}, dtx{tx, lane == 19 ? 1.0f : 0.0f}, dty{ty, lane == 20 ? 1.0f : 0.0f};
+#pragma unroll
+        for (int o = 0; o < 3 * kNumJoints; ++o) dJ[o] = Dual{J[o], lane == 21 + o ? 1.0f : 0.0f};
+        float grad = 0.0f;
+        pose_chain_t<Dual>(a.lay, a.parents, dpose, dJ, drot, dscale, dtx, dty, [&](int i, Dual val) { grad += val.d * g_out[i]; });
+        if (lane < 3) {
+            if (a.lay.neck_n == 3) gp[a.lay.neck_off + lane] = grad;
+        } else if (lane < 6) {
+            if (a.lay.jaw_n == 3) gp[a.lay.jaw_off + lane - 3] = grad;
+        } else if (lane < 12) {
+            if (a.lay.eye_n == 6) gp[a.lay.eye_off + lane - 6] = grad;
+        } else if (lane < 18) {
+            gp[a.lay.rot_off + lane - 12] = grad;
+        } else if (lane == 18) {
+            gp[a.lay.scale_off] = grad;
+        } else if (lane < 21) {
+            gp[a.lay.trans_off + lane - 19] = grad;
+        } else {
+            g_joint[lane - 21] = grad;
+        }
+    } else if (lane == kChainInputs) {
+        gp[a.lay.trans_off + 2] = 0.0f;  // translation z reaches no output
+    }
+    __syncthreads();
+    // betas: the GEMM's share plus the joints' share, Jdirs^T . dJ
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+        const int l = lane + 64 * k;
+        if (l >= a.n_betas) continue;
+        float g = a.g_inputs[(size_t)b * n_in + l];
+#pragma unroll
+        for (int o = 0; o < 3 * kNumJoints; ++o) g += a.jdirs[(size_t)o * a.n_betas + l] * g_joint[o];
+        if (l < a.max_shape) {
+            if (l < a.lay.shape_n) gp[a.lay.shape_off + l] = g;
+        } else if (l - a.max_shape < a.lay.expr_n) {
+            gp[a.lay.expr_off + l - a.max_shape] = g;
+        }
+    }
+}
+
 }  // namespace
+
+dad3d_status launch_pose_chain(const ChainArgs& a, bool vjp, hipStream_t s) {
+    if (a.batch <= 0) return DAD3D_OK;
+    if (vjp) hipLaunchKernelGGL(pose_chain_kernel<true>, dim3(a.batch), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(pose_chain_kernel<false>, dim3(a.batch), dim3(64), 0, s, a);
+    DAD3D_HIP_TRY(hipGetLastError());
+    return DAD3D_OK;
+}
 
 dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s) {
     if (a.batch <= 0) return DAD3D_OK;

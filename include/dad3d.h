@@ -121,6 +121,20 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
                                          const float* grad_verts3d, const float* grad_proj, float* grad_posed,
                                          float* grad_consts, void* stream);
 
+/* Per-image half of the same differentiable decode: everything between a params row and the operands of the per-vertex
+ * work (flame.py:191-210 betas / full_pose assembly, smplx batch_rodrigues + batch_rigid_transform + vertices2joints,
+ * model/utils.py:92-101 rot_mat_from_6dof, head_mesh.py:39-41 scale / translation).
+ *   inputs  [B, K] fp32, K = dad3d_flame_num_chain_inputs() = 400 + 36: [betas | pose feature], the A operand of the
+ *           blend-shape contraction (v_posed = template + inputs . basis)
+ *   consts  [B,72] as described above
+ * ..._backward is its vector-Jacobian product: grad_params [B,P] (every entry written; translation z gets 0) from
+ * grad_inputs [B,K] and grad_consts [B,72]. The derivative is taken with dual numbers over the SAME device code that
+ * computes the forward values (one lane per input direction), so the two cannot drift apart. */
+int dad3d_flame_num_chain_inputs(const dad3d_flame* h);
+dad3d_status dad3d_flame_pose_chain(dad3d_flame* h, const float* params, int batch, float* inputs, float* consts, void* stream);
+dad3d_status dad3d_flame_pose_chain_backward(dad3d_flame* h, const float* params, int batch, const float* grad_inputs,
+                                             const float* grad_consts, float* grad_params, void* stream);
+
 /* Same, HOST buffers in and out (synchronous; PCIe-inclusive convenience for non-HIP callers). */
 dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
                                      float* proj, float* lmk_xy, int32_t* lmk_px);

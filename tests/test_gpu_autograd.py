@@ -105,7 +105,7 @@ def test_reference_losses_values_and_gradients(flame_model, flame_consts, static
         v_ref = flame_ref.vertices_3d(flame_consts, p_ref * 1.0, zero_rotation=True)
         ref = torch.stack([fn(normalize_to_cube(v_ref[:, i]), normalize_to_cube(tgt3d[:, i])) * w for w, i in zip(*regions)]).sum()
         ref.backward()
-        assert abs(float(val) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+        assert abs(float(val.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
         assert close(p.grad, p_ref.grad)
         # ReprojectionLoss (reprojection_loss.py:22-46), list target form
         loss = ReprojectionLoss(crit, batch, FLAME_CONSTS, 256, regions, **kw)
@@ -116,7 +116,7 @@ def test_reference_losses_values_and_gradients(flame_model, flame_consts, static
         pr_ref = flame_ref.reprojected_vertices(flame_consts, p_ref * 1.0)
         ref = torch.stack([fn(pr_ref[:, i], tgt2d[:, i]) * w for w, i in zip(*regions)]).sum()
         ref.backward()
-        assert abs(float(val) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref)))
+        assert abs(float(val.detach()) - float(ref.detach())) <= 1e-4 * max(1.0, abs(float(ref.detach())))
         assert close(p.grad, p_ref.grad)
     with pytest.raises(ValueError, match="Unsupported discrepancy loss type"):
         Vertices3DLoss("huber", batch, FLAME_CONSTS, regions, **kw)
@@ -132,3 +132,57 @@ def test_c_abi_backward_argument_errors(hm):
     assert st != 0 and b"no upstream gradient" in lib.dad3d_last_error()
     st = lib.dad3d_flame_decode_backward(None, 1, 0, c72.data_ptr(), buf.data_ptr(), buf.data_ptr(), None, buf.data_ptr(), c72.data_ptr(), None)
     assert st != 0
+
+
+def _configs(flame_model, static):
+    """(HeadMesh, params) for the shipped constants, a full pose (neck + eyeballs) and narrow shape / expression widths."""
+    rng = np.random.default_rng(3)
+    base = synthetic.synthetic_params(5, seed=9)
+    full = {"shape": 300, "expression": 100, "jaw": 3, "rotation": 6, "eyeballs": 6, "neck": 3, "translation": 3, "scale": 1}
+    narrow = {"shape": 100, "expression": 50, "jaw": 3, "rotation": 6, "eyeballs": 0, "neck": 0, "translation": 3, "scale": 1}
+    kw = dict(flame_model=flame_model, static=static, device=0)
+    yield HeadMesh(**kw), base, FLAME_CONSTS
+    yield (HeadMesh(flame_config=full, **kw),
+           np.concatenate([base[:, :409], 0.2 * rng.standard_normal((5, 9)).astype(np.float32), base[:, 409:]], axis=1), full)
+    yield HeadMesh(flame_config=narrow, **kw), np.concatenate([base[:, :100], base[:, 300:350], base[:, 400:]], axis=1), narrow
+
+
+def test_chain_kernels_match_the_torch_statement_of_the_chain(flame_model, static):
+    """`dad3d_flame_pose_chain` against `autograd.pose_chain` (itself pinned to the oracle on CPU) and its dual-number
+    backward against torch autograd over that statement, for three constants layouts."""
+    from dad_3dheads_amd import autograd as ag
+
+    lib = _lib.load()
+    for mesh, params_np, consts in _configs(flame_model, static):
+        layer = mesh.flame
+        tables = layer.decode_tables()
+        p = torch.from_numpy(np.ascontiguousarray(params_np)).cuda().requires_grad_(True)
+        b = p.shape[0]
+        chain = ag.pose_chain(tables, consts, p)
+        k = lib.dad3d_flame_num_chain_inputs(layer._handle)
+        assert k == chain["inputs"].shape[1] == 436
+        inputs = torch.empty((b, k), device="cuda")
+        c72 = torch.empty((b, 72), device="cuda")
+        _lib.check(lib.dad3d_flame_pose_chain(layer._handle, p.data_ptr(), b, inputs.data_ptr(), c72.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert (inputs - chain["inputs"]).abs().max() < 2e-6
+        assert (c72 - chain["consts"]).abs().max() < 2e-6
+        gen = torch.Generator().manual_seed(8)
+        g_in, g_c = torch.randn((b, k), generator=gen).cuda(), torch.randn((b, 72), generator=gen).cuda()
+        (g_ref,) = torch.autograd.grad([chain["inputs"], chain["consts"]], [p], [g_in, g_c])
+        g = torch.full_like(p.detach(), float("nan"))  # every entry must be written
+        _lib.check(lib.dad3d_flame_pose_chain_backward(layer._handle, p.data_ptr(), b, g_in.data_ptr(), g_c.data_ptr(), g.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(g).all())
+        assert float((g - g_ref).abs().max()) <= 2e-5 * float(g_ref.abs().max())
+
+
+def test_full_pose_and_narrow_layout_gradients_match_oracle(flame_model, flame_consts, static):
+    for mesh, params_np, consts in list(_configs(flame_model, static))[1:]:
+        params = torch.from_numpy(np.ascontiguousarray(params_np))
+        w = torch.randn((params.shape[0], 5023, 3), generator=torch.Generator().manual_seed(4))
+        p_ref = params.clone().requires_grad_(True)
+        (flame_ref.reprojected_vertices(flame_consts, p_ref * 1.0, to_2d=False, consts=consts) * w).sum().backward()
+        p = params.clone().cuda().requires_grad_(True)
+        (mesh.reprojected_vertices(p * 1.0, to_2d=False) * w.cuda()).sum().backward()
+        assert close(p.grad, p_ref.grad)
