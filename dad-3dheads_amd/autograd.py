@@ -6,15 +6,17 @@ decode (`dad3d_flame_decode`) and the backward pass is split where the sizes spl
 
 * everything per VERTEX (5023 x B) runs in the HIP library: `dad3d_flame_decode_backward` (csrc/flame_backward.hip)
   turns dL/d(3d_vertices), dL/d(projected) into dL/d(v_posed) [B,V,3] and the per-image sums dL/d(consts) [B,72];
-* the two contractions with the blend-shape basis are plain library GEMMs (rocBLAS through `torch.matmul`):
-  v_posed = template + [betas | pose feature] @ basis, and dL/d[betas | pose feature] = dL/d(v_posed) @ basis^T;
+* v_posed (the skinning's input) is saved by the forward launch itself (`dad3d_flame_decode_posed`, one more store per
+  vertex); the one contraction of the backward pass with the blend-shape basis, dL/d[betas | pose feature] =
+  dL/d(v_posed) @ basis^T, is a plain library GEMM (rocBLAS through `torch.matmul`);
 * the 72 per-image constants (joint transforms, 6-DoF rotation, scale, translation) are a few hundred flops per image
   of Rodrigues / kinematic chain / Gram-Schmidt: `dad3d_flame_pose_chain` evaluates them and
   `dad3d_flame_pose_chain_backward` differentiates them with dual numbers over the same device code (one launch each
   instead of the ~300 small kernels of a torch graph). `pose_chain` below states the same chain with torch ops; the
   tests use it (and torch's autograd over it) to check the two kernels, and on CPU to pin the layout against the oracle.
 
-A backward pass is five launches: chain, GEMM, per-vertex kernel, GEMM, chain VJP.
+A backward pass is four launches (+ one that adds partial sums for small batches): chain, per-vertex kernel, GEMM,
+chain VJP.
 
 Formulas restated from the published smplx algorithm (`lbs.py`: batch_rodrigues, batch_rigid_transform) and
 `model_training/model/utils.py:92-101` (rot_mat_from_6dof); checked against the oracle's autograd in the tests.
@@ -132,12 +134,23 @@ class _Decode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params: Tensor, layer, want_v3: bool, want_proj: bool, zero_rot: bool, to_2d: bool):
         staged = params.detach().to(layer.torch_device, torch.float32).contiguous()
-        out = layer.decode(staged, verts3d=want_v3, proj=want_proj, to_2d=to_2d, zero_rot=zero_rot)
-        ctx.layer, ctx.flags = layer, (_lib.ZERO_ROTATION if zero_rot else 0) | (_lib.TO_2D if to_2d else 0)
+        if staged.data_ptr() == params.data_ptr():
+            # the caller may write into its tensor afterwards (reprojected_vertices zeroes tz in place, head_mesh.py:41):
+            # keep our own 1.6 KB per image rather than a view whose version counter that write would bump
+            staged = staged.clone()
+        dev, b, v = layer.torch_device, staged.shape[0], layer.n_verts
+        flags = (_lib.ZERO_ROTATION if zero_rot else 0) | (_lib.TO_2D if to_2d else 0)
+        d_v3 = torch.empty((b, v, 3), dtype=torch.float32, device=dev) if want_v3 else None
+        d_pj = torch.empty((b, v, 2 if to_2d else 3), dtype=torch.float32, device=dev) if want_proj else None
+        posed = torch.empty((b, v * 3), dtype=torch.float32, device=dev)  # v_posed, kept for the backward pass
+        _lib.check(layer._lib.dad3d_flame_decode_posed(
+            layer._handle, staged.data_ptr(), b, flags, d_v3.data_ptr() if want_v3 else None,
+            d_pj.data_ptr() if want_proj else None, posed.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        ctx.layer, ctx.flags = layer, flags
         ctx.src_device = params.device
-        ctx.save_for_backward(staged)
-        v3 = out["verts3d"].to(params.device) if want_v3 else params.new_empty(0)
-        pj = out["proj"].to(params.device) if want_proj else params.new_empty(0)
+        ctx.save_for_backward(staged, posed)
+        v3 = d_v3.to(params.device) if want_v3 else params.new_empty(0)
+        pj = d_pj.to(params.device) if want_proj else params.new_empty(0)
         if not want_v3:
             ctx.mark_non_differentiable(v3)
         if not want_proj:
@@ -147,7 +160,7 @@ class _Decode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_v3: Optional[Tensor], g_pj: Optional[Tensor]):
         layer = ctx.layer
-        (staged,) = ctx.saved_tensors
+        staged, posed = ctx.saved_tensors
         dev, b, v = layer.torch_device, staged.shape[0], layer.n_verts
         tables = layer.decode_tables()
 
@@ -166,7 +179,6 @@ class _Decode(torch.autograd.Function):
             inputs = torch.empty((b, tables.basis.shape[0]), dtype=torch.float32, device=dev)
             consts = torch.empty((b, N_CONSTS), dtype=torch.float32, device=dev)
             _lib.check(lib.dad3d_flame_pose_chain(handle, staged.data_ptr(), b, inputs.data_ptr(), consts.data_ptr(), stream))
-            posed = torch.addmm(tables.template, inputs, tables.basis)  # [B,3V] = v_posed, library GEMM
             g_posed = torch.empty_like(posed)
             g_consts = torch.empty_like(consts)
             _lib.check(lib.dad3d_flame_decode_backward(

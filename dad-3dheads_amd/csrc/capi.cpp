@@ -60,6 +60,8 @@ struct dad3d_flame {
     float image_size = 256.f;
     std::shared_ptr<FlameConsts> c;
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
+    float* d_bwd_partials = nullptr;  // [cap][kBackwardMaxSplit][72] scratch of dad3d_flame_decode_backward
+    int bwd_cap = 0;
     int n_lmk = 0;
     float* d_imgc = nullptr;
     unsigned* d_sync = nullptr;   // [0] arrival counter, [1] time-out counter; [4], [5], [last]: device-epoch launches
@@ -216,7 +218,7 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
 void dad3d_flame_destroy(dad3d_flame* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
-    for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc})
+    for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials})
         if (p) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
@@ -232,6 +234,8 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->d_lmk_head = h->d_lmk_next = nullptr;
     h->d_imgc = nullptr;
     h->d_sync = nullptr;
+    h->d_bwd_partials = nullptr;
+    h->bwd_cap = 0;
     h->arrive_total = 0;
     h->cap_nbb = 0;
     h->profiling = false;
@@ -281,8 +285,8 @@ dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n
     return DAD3D_OK;
 }
 
-dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
-                                float* lmk_xy, int32_t* lmk_px, void* stream) {
+static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+                                float* lmk_xy, int32_t* lmk_px, float* posed, void* stream) {
     DAD3D_REQUIRE(h, "dad3d_flame_decode: null handle");
     DAD3D_REQUIRE(batch >= 0, "dad3d_flame_decode: negative batch");
     if (batch == 0) return DAD3D_OK;
@@ -310,6 +314,7 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     da.proj = proj;
     da.lmk_xy = lmk_xy;
     da.lmk_px = lmk_px;
+    da.posed = posed;
     da.trace = h->d_trace;
     da.lay = h->lay;
     std::copy(h->parents, h->parents + kNumJoints, da.parents);
@@ -340,6 +345,16 @@ dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsign
     if (!device_epoch) h->arrive_total = da.arrive_target;  // committed only once the launch was accepted
     if (h->profiling) ++h->prof_launches;
     return DAD3D_OK;
+}
+
+dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+                                float* lmk_xy, int32_t* lmk_px, void* stream) {
+    return decode_impl(h, params, batch, flags, verts3d, proj, lmk_xy, lmk_px, nullptr, stream);
+}
+
+dad3d_status dad3d_flame_decode_posed(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+                                      float* posed, void* stream) {
+    return decode_impl(h, params, batch, flags, verts3d, proj, nullptr, nullptr, posed, stream);
 }
 
 dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
@@ -425,6 +440,20 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
     ba.n_verts = h->n_verts;
     ba.image_size = h->image_size;
     ba.flags = flags;
+    // small batches: split every image over several workgroups (about one per CU), partial sums added in fixed order
+    ba.nsplit = std::max(1, std::min(kBackwardMaxSplit, 256 / batch));
+    if (ba.nsplit > 1) {
+        if (batch > h->bwd_cap) {
+            DAD3D_HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(h->d_bwd_partials);
+            h->d_bwd_partials = nullptr;
+            h->bwd_cap = 0;
+            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_bwd_partials),
+                                    (size_t)batch * kBackwardMaxSplit * kBackwardConsts * sizeof(float)));
+            h->bwd_cap = batch;
+        }
+        ba.partials = h->d_bwd_partials;
+    }
     return launch_flame_backward(ba, static_cast<hipStream_t>(stream));
 }
 

@@ -99,6 +99,8 @@ struct DecodeArgs {
     unsigned spin_limit;
     float image_size;
     unsigned flags;
+    float* posed;            // [B,V,3] v_posed (before skinning) for the backward pass, or null. Last on purpose: the
+                             // inference instantiations never read it and their kernarg offsets stay what they were
 };
 
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s);
@@ -114,11 +116,13 @@ struct BackwardArgs {
     const float* g_proj;     // [B,V,2|3] or null
     float* g_posed;          // [B,V,3]
     float* g_consts;         // [B][72]
-    int batch, n_verts;
+    float* partials;         // [B][nsplit][72] scratch when nsplit > 1
+    int batch, n_verts, nsplit;
     float image_size;
     unsigned flags;          // DAD3D_ZERO_ROTATION | DAD3D_TO_2D | DAD3D_FLIP_Z as passed to the forward call
 };
 dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s);
+constexpr int kBackwardMaxSplit = 8;
 
 // Per-image chain (flame_backward.hip): forward writes `inputs` and `consts`; vjp reads g_inputs / g_consts, writes g_params.
 struct ChainArgs {

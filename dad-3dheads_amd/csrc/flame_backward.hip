@@ -13,9 +13,10 @@
 // The 72 constants are tiny functions of (pose, joints, rot6d, scale, translation); their own derivatives are taken
 // by the host mirror (dad_3dheads_amd/autograd.py), which also owns the two plain GEMMs.
 //
-// One workgroup per image walks all vertices (coalesced 12-byte records), keeps its 72 partial sums in registers and
-// reduces them once at the end: no atomics, so the gradient is bit-reproducible run to run. HBM-bound streaming:
-// per image 3 x 60 KB read (v_posed, the two gradients), 60 KB written.
+// A workgroup walks a contiguous share of one image's vertices (coalesced 12-byte records), keeps its 72 partial sums
+// in registers and reduces them once at the end; an image is split over `nsplit` workgroups so that small batches
+// still fill the chip, and a second tiny kernel adds the partials in a fixed order: no atomics, so the gradient is
+// bit-reproducible run to run. HBM-bound streaming: per image 3 x 60 KB read (v_posed, the two gradients), 60 KB written.
 #include "common.hpp"
 
 namespace dad3d {
@@ -35,7 +36,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 __global__ __launch_bounds__(kBwdThreads) void flame_backward_kernel(BackwardArgs a) {
     __shared__ float c[kBackwardConsts];
     __shared__ float red[kBwdWaves][kBackwardConsts];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < kBackwardConsts) c[tid] = a.consts[(size_t)b * kBackwardConsts + tid];
     __syncthreads();
     const bool zero_rot = (a.flags & DAD3D_ZERO_ROTATION) != 0, to2d = (a.flags & DAD3D_TO_2D) != 0;
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(kBwdThreads) void flame_backward_kernel(BackwardArg
 #pragma unroll
     for (int i = 0; i < kBackwardConsts; ++i) acc[i] = 0.0f;
 
-    for (int v = tid; v < a.n_verts; v += kBwdThreads) {
+    const int per_part = (a.n_verts + a.nsplit - 1) / a.nsplit;
+    const int v_end = min(a.n_verts, (part + 1) * per_part);
+    for (int v = part * per_part + tid; v < v_end; v += kBwdThreads) {
         const float* w8 = a.weights8 + (size_t)v * 8;
         const float4 wa = *reinterpret_cast<const float4*>(w8);
         const float w[kNumJoints] = {wa.x, wa.y, wa.z, wa.w, w8[4]};
@@ -117,8 +120,17 @@ __global__ __launch_bounds__(kBwdThreads) void flame_backward_kernel(BackwardArg
         float t = 0.0f;
 #pragma unroll
         for (int wv = 0; wv < kBwdWaves; ++wv) t += red[wv][tid];
-        a.g_consts[(size_t)b * kBackwardConsts + tid] = t;
+        (a.nsplit > 1 ? a.partials + ((size_t)b * a.nsplit + part) * kBackwardConsts : a.g_consts + (size_t)b * kBackwardConsts)[tid] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void add_partials_kernel(BackwardArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (image, constant)
+    if (i >= a.batch * kBackwardConsts) return;
+    const int b = i / kBackwardConsts, c = i - b * kBackwardConsts;
+    float t = 0.0f;
+    for (int s = 0; s < a.nsplit; ++s) t += a.partials[((size_t)b * a.nsplit + s) * kBackwardConsts + c];
+    a.g_consts[i] = t;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -392,7 +404,9 @@ dad3d_status launch_pose_chain(const ChainArgs& a, bool vjp, hipStream_t s) {
 
 dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s) {
     if (a.batch <= 0) return DAD3D_OK;
-    hipLaunchKernelGGL(flame_backward_kernel, dim3(a.batch), dim3(kBwdThreads), 0, s, a);
+    hipLaunchKernelGGL(flame_backward_kernel, dim3(a.batch, a.nsplit), dim3(kBwdThreads), 0, s, a);
+    if (a.nsplit > 1)
+        hipLaunchKernelGGL(add_partials_kernel, dim3((a.batch * kBackwardConsts + 255) / 256), dim3(256), 0, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

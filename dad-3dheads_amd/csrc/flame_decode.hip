@@ -425,7 +425,7 @@ struct Parts {  // A-image parts in MFMA groups of 16 k: [0,6) [6,14) [14,KG)
 
 // RB = 16-image MFMA row blocks per workgroup: 4, or 1 for launches of at most 16 images (a single image is how the
 // reference calls this path: a quarter of the MFMAs, 8.3 us instead of 13.4 us per launch).
-template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH, int RB>
+template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH, int RB, bool POSED = false>
 __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Two ways to tell the decode role how far the arrival counter must get. Normally the HOST keeps the running
@@ -741,6 +741,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     float* const pj_base = a.proj ? a.proj + ((size_t)wimg * a.n_verts + v0) * pc : nullptr;
     float* const lx_base = a.lmk_xy ? a.lmk_xy + (size_t)wimg * a.n_lmk * 2 : nullptr;
     int* const lp_base = a.lmk_px ? a.lmk_px + (size_t)wimg * a.n_lmk * 2 : nullptr;
+    // POSED (training callers only, its own instantiation: the inference kernel does not carry the branch)
+    float* const ps_base = POSED ? a.posed + ((size_t)wimg * a.n_verts + v0) * 3 : nullptr;
     const unsigned nv = (unsigned)a.n_verts, nl = (unsigned)a.n_lmk;
     auto put_landmark = [&](unsigned li, int slot, float ox, float oy) {
         const unsigned off = (li * nl + (unsigned)slot) * 2u;
@@ -793,6 +795,10 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         const float ry = ra.w * px + rb.x * py + rb.y * pz;
         const float rz = rb.z * px + rb.w * py + rc.x * pz;
         const unsigned lv = (unsigned)li * nv + (unsigned)j;  // (image, vertex) relative to the wave's bases
+        if (POSED) {  // v_posed is the operand of the backward pass
+            float* d = ps_base + lv * 3u;
+            d[0] = x, d[1] = y, d[2] = z;
+        }
         if (v3_base) {
             float* d = v3_base + lv * 3u;
             d[0] = zero_rot ? px : rx;
@@ -823,17 +829,17 @@ size_t flame_decode_lds_bytes(int kgroups) {
     return (size_t)(kgroups == 26 ? DecodeLds<26>::total : DecodeLds<28>::total) * sizeof(float);
 }
 
-template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH, int RB>
+template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH, int RB, bool POSED = false>
 static dad3d_status launch_decode_r(const DecodeArgs& a, hipStream_t s) {
     static bool attr_done = false;
     const size_t lds = flame_decode_lds_bytes(KG);
     if (!attr_done) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB, POSED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8 * a.nbb;
-    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB, POSED>), dim3(grid), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }
@@ -846,6 +852,13 @@ static dad3d_status launch_decode_e(const DecodeArgs& a, hipStream_t s) {
 
 template <int KG, bool JAW_ONLY, bool CONTIG>
 static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
+    if (a.posed) {  // training forward: one instantiation (host epoch, four row blocks) that also stores v_posed
+        if (a.flags & kDeviceEpoch) {
+            set_error("dad3d_flame_decode_posed cannot be captured into a graph");
+            return DAD3D_E_UNSUPPORTED;
+        }
+        return launch_decode_r<KG, JAW_ONLY, CONTIG, false, 4, true>(a, s);
+    }
     return (a.flags & kDeviceEpoch) ? launch_decode_e<KG, JAW_ONLY, CONTIG, true>(a, s)
                                     : launch_decode_e<KG, JAW_ONLY, CONTIG, false>(a, s);
 }

@@ -104,6 +104,12 @@ int dad3d_flame_num_landmarks(const dad3d_flame* h);
 dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                 float* lmk_xy, int32_t* lmk_px, void* stream);
 
+/* The same launch for callers that will differentiate: additionally stores posed [B,V,3] = v_posed (template + blend
+ * shapes + pose correctives, i.e. smplx lbs before skinning), the operand dad3d_flame_decode_backward needs. No
+ * landmark outputs. */
+dad3d_status dad3d_flame_decode_posed(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+                                      float* posed, void* stream);
+
 /* Vertex half of the BACKWARD pass of dad3d_flame_decode, for the reference's training callers that differentiate
  * through HeadMesh (model_training/losses/vertices_3d_loss.py:41 `vertices_3d(..., zero_rotation=True)`,
  * reprojection_loss.py:33 `reprojected_vertices(..., to_2d=True)`; the reference gets these gradients from torch

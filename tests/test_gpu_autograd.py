@@ -64,6 +64,25 @@ def test_reprojection_gradient_and_in_place_side_effect(hm, flame_consts, to_2d)
         hm.reprojected_vertices(params.clone().cuda().requires_grad_(True))
 
 
+def test_both_losses_on_one_prediction_tensor(hm, flame_consts):
+    """The training loop hands the SAME network output to both losses: vertices_3d saves it, reprojected_vertices then
+    writes tz := 0 into it in place -- that must not invalidate the first graph."""
+    params = torch.from_numpy(synthetic.synthetic_params(4, seed=21))
+    gen = torch.Generator().manual_seed(6)
+    wv, wp = torch.randn((4, 5023, 3), generator=gen), torch.randn((4, 5023, 2), generator=gen)
+    p_ref = params.clone().requires_grad_(True)
+    q_ref = p_ref * 1.0
+    v_ref = flame_ref.vertices_3d(flame_consts, q_ref, zero_rotation=True)
+    pr_ref = flame_ref.reprojected_vertices(flame_consts, q_ref)
+    ((v_ref * wv).sum() + (pr_ref * wp).sum() * 1e-2).backward()
+    p = params.clone().cuda().requires_grad_(True)
+    q = p * 1.0
+    v = hm.vertices_3d(q, zero_rotation=True)
+    pr = hm.reprojected_vertices(q)
+    ((v * wv.cuda()).sum() + (pr * wp.cuda()).sum() * 1e-2).backward()
+    assert close(p.grad, p_ref.grad)
+
+
 def test_cpu_tensors_round_trip_and_backward_is_reproducible(hm, flame_consts):
     params = torch.from_numpy(synthetic.synthetic_params(4, seed=9))
     w = torch.randn((4, 5023, 3), generator=torch.Generator().manual_seed(3))
