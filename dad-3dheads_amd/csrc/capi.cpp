@@ -336,6 +336,9 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     const bool device_epoch = capture != hipStreamCaptureStatusNone;
     da.arrive_target = h->arrive_total + (unsigned)batch;  // every image's pose wave arrives once per launch
     da.spin_limit = 1u << 20;
+#ifdef DAD3D_DIAG_SPIN_ENV  // diagnostics builds only (tools/attic): hand-off spin limit from the environment
+    if (const char* e = getenv("DAD3D_SPIN_LIMIT")) da.spin_limit = (unsigned)atoi(e);
+#endif
     da.image_size = h->image_size;
     da.flags = (flags & 0xFFu) | (device_epoch ? kDeviceEpoch : 0u);
     dad3d_status st;
