@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostics for the eight-mma-wave lead (profiles/r01_kernel_log.md): one batch-64 launch through the alternate
-library tools/attic/libdad3d_hip_mw8.so, timed, compared with the batch-16 path of the same library."""
+"""Diagnostics for the decode-kernel leads (profiles/r01_kernel_log.md): three batch-64 launches through an ALTERNATE
+library (tools/attic/build_alt.sh -> tools/attic/alt.so, or $DAD3D_LIB_PATH), timed, and compared with the batch-16
+path of the same library (which takes the unchanged small-batch instantiation). Run under `timeout 25`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from dad_3dheads_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdad3d_hip_mw8.so")
+_lib.LIB_PATH = os.environ.get("DAD3D_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "alt.so")
 from dad_3dheads_amd import landmarks, synthetic
 from dad_3dheads_amd.head_mesh import HeadMesh
 import ctypes as C
