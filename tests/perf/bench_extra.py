@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dad_3dheads_amd import landmarks, synthetic  # noqa: E402
 from dad_3dheads_amd.head_mesh import HeadMesh  # noqa: E402
 from dad_3dheads_amd.Sim3DR import Mesh  # noqa: E402

@@ -3,7 +3,7 @@
 (`Vertices3DLoss` with zero_rotation, `ReprojectionLoss` to_2d) on one MI355X, and the same through torch autograd
 over the CPU oracle (= how the reference obtains these gradients) on this host. Prints one JSON object.
 
-    python tools/bench_train.py [batch ...]      default 64 256
+    python tests/perf/bench_train.py [batch ...]      default 64 256
 """
 import json
 import os
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dad_3dheads_amd import landmarks, synthetic  # noqa: E402
 from dad_3dheads_amd.flame import FLAME_CONSTS  # noqa: E402
 from dad_3dheads_amd.head_mesh import HeadMesh  # noqa: E402
