@@ -87,3 +87,33 @@ def load_reference_head_mesh(model, flame_config=None, image_size: int = 256):
     ref_flame.get_flame_model = lambda flame_path=None: Struct(**fields)
     with torch.no_grad():
         return HeadMesh(flame_config=flame_config, image_size=image_size)
+
+
+def load_reference_losses(model):
+    """The reference's own `Vertices3DLoss` / `ReprojectionLoss` classes (model_training/losses/*.py, unmodified),
+    wired to `model` like `load_reference_head_mesh`. The package `__init__` (which pulls in unrelated losses with more
+    uninstalled imports) is bypassed by registering an empty package module; `model_training/utils.py` gets stand-ins
+    for `omegaconf`, `coloredlogs` and `hydra.utils.get_original_cwd`, none of which the loss path calls."""
+    load_reference_head_mesh(model)  # stubs, sys.path and the patched get_flame_model
+
+    def _mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    if "omegaconf" not in sys.modules:
+        oc = _mod("omegaconf")
+        oc.OmegaConf, oc.DictConfig = type("OmegaConf", (), {}), dict
+    if "coloredlogs" not in sys.modules:
+        cl = _mod("coloredlogs")
+        cl.DEFAULT_FIELD_STYLES, cl.install = {}, (lambda *a, **k: None)
+    if not hasattr(sys.modules["hydra.utils"], "get_original_cwd"):
+        sys.modules["hydra.utils"].get_original_cwd = os.getcwd
+    if "model_training.losses" not in sys.modules:
+        pkg = _mod("model_training.losses")
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "model_training", "losses")]
+    import importlib
+
+    v3d = importlib.import_module("model_training.losses.vertices_3d_loss")
+    rep = importlib.import_module("model_training.losses.reprojection_loss")
+    return v3d.Vertices3DLoss, rep.ReprojectionLoss
