@@ -69,6 +69,33 @@ __device__ __forceinline__ void rodrigues(const float r[3], float R[9]) {
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * K[i] + c1 * KK[i];
 }
 
+// R - I of smplx.lbs.batch_rodrigues for one joint, written for the decode role's start-up path (every workgroup needs the
+// pose feature of its 64 images before the GEMM's last group): K.K = a a^T - |a|^2 I, so R - I = sin*K + (1-cos)*(a a^T - |a|^2 I)
+// without forming 1 + x - 1 (the reference's own rounding of that is 6e-8); 1/angle from v_rsq_f32 (1 ulp). ~90 VALU
+// instructions instead of ~300 (correctly rounded sqrt and three divisions): an instruction of a wave that shares its SIMD
+// with a streaming mma wave costs the matrix pipe ~8 cycles.
+__device__ __forceinline__ void rodrigues_minus_identity(const float r[3], float D[9]) {
+    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
+    const float n2 = ex * ex + ey * ey + ez * ez;
+    const float inv = __builtin_amdgcn_rsqf(n2);
+    const float angle = n2 * inv;
+    const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
+    float s, c;
+    sincosf(angle, &s, &c);
+    const float c1 = 1.0f - c;
+    const float aa = x * x + y * y + z * z;
+    const float cxy = c1 * (x * y), cxz = c1 * (x * z), cyz = c1 * (y * z);
+    D[0] = c1 * (x * x - aa);
+    D[1] = cxy - s * z;
+    D[2] = cxz + s * y;
+    D[3] = cxy + s * z;
+    D[4] = c1 * (y * y - aa);
+    D[5] = cyz - s * x;
+    D[6] = cxz - s * y;
+    D[7] = cyz + s * x;
+    D[8] = c1 * (z * z - aa);
+}
+
 __device__ __forceinline__ void identity3(float R[9]) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
@@ -639,18 +666,16 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
 #pragma unroll
                     for (int i = 0; i < L::K - kNumBeta; ++i) tail[i] = 0.0f;
                     if (tail_live) {
-                        float R[kNumJoints][9];
-                        joint_rotations(pose_in, a.lay, R);
                         if (JAW_ONLY) {
-#pragma unroll
-                            for (int i = 0; i < 9; ++i) tail[i] = R[2][i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+                            if (a.lay.jaw_n == 3) rodrigues_minus_identity(pose_in.jaw, tail);
                             tail[9] = 1.0f;
                         } else {
-#pragma unroll
-                            for (int jj = 1; jj < kNumJoints; ++jj)
-#pragma unroll
-                                for (int i = 0; i < 9; ++i)
-                                    tail[(jj - 1) * 9 + i] = R[jj][i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+                            if (a.lay.neck_n == 3) rodrigues_minus_identity(pose_in.neck, tail);
+                            if (a.lay.jaw_n == 3) rodrigues_minus_identity(pose_in.jaw, tail + 9);
+                            if (a.lay.eye_n == 6) {
+                                rodrigues_minus_identity(pose_in.eyes, tail + 18);
+                                rodrigues_minus_identity(pose_in.eyes + 3, tail + 27);
+                            }
                             tail[36] = 1.0f;
                         }
                     }

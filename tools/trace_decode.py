@@ -49,6 +49,13 @@ print("per-wave total mean", (t[..., 5] - t[..., 0]).mean())
 if full[..., 8].max() > 0:  # fine stamps of a diagnostics build (DAD3D_ABLATE & 64)
     m = full[:, :4]
     print("mma fine stamps (ticks since GEMM start): ", [round(float((m[..., k] - m[..., 2]).mean())) for k in range(8, 15)], " GEMM end", round(float((m[..., 3] - m[..., 2]).mean())))
+    if m[..., 16].max() > 0:
+        g = np.stack([(m[..., 16 + k] - m[..., 2]).mean() for k in range(13)] + [(m[..., 3] - m[..., 2]).mean()])
+        print("mma cycles per MFMA by pair of groups (0-1, 2-3, ...):", [round(float(x) / 32, 1) for x in np.diff(g)])
+    f = full[:, 4:]
+    print("feeder fine stamps (ticks since wave start): stamp1 %d, stamp2 %d, s8 %d, s9 %d, s10 %d, all parts published %d" % tuple(
+        round(float((f[..., k] - f[..., 0]).mean())) for k in (1, 2, 8, 9, 10, 3)))
+    print("mma: wave start -> part0 seen %d" % round(float((m[..., 2] - m[..., 0]).mean())))
 pl = pose[..., 0] > 0
 print("pose role waves: compute %.0f  store+drain %.0f  arrive %.0f ticks (mean over %d waves)" % (
     (pose[..., 1] - pose[..., 0])[pl].mean(), (pose[..., 2] - pose[..., 1])[pl].mean(), (pose[..., 3] - pose[..., 2])[pl].mean(), pl.sum()))
