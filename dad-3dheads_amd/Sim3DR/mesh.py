@@ -23,6 +23,13 @@ def _chk(t: Tensor, dtype, ndim: int, name: str, dev: torch.device) -> Tensor:
 
 
 class Mesh:
+    def _verts(self, vertices: Tensor, name: str = "vertices") -> Tensor:
+        """[B, nver, 3] float32 on this mesh's device -- the kernels index every vertex the triangle list names."""
+        v = _chk(vertices, torch.float32, 3, name, self.torch_device)
+        if tuple(v.shape[1:]) != (self.nver, 3):
+            raise ValueError(f"{name}: expected [B, {self.nver}, 3], got {tuple(v.shape)}")
+        return v
+
     def __init__(self, triangles, nver: int, device: Optional[int] = None):
         tri = np.ascontiguousarray(np.asarray(triangles))
         if tri.dtype != np.int32:
@@ -55,24 +62,30 @@ class Mesh:
     # -- normals -----------------------------------------------------------------------------------
     def get_normal(self, vertices: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
         """`_get_normal` per image: vertices [B,nver,3] -> unit vertex normals [B,nver,3]."""
-        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        v = self._verts(vertices)
         if out is None:
             if accumulate:
                 raise ValueError("accumulate=True needs `out`")
             out = torch.empty_like(v)
-        _chk(out, torch.float32, 3, "out", self.torch_device)
+        self._verts(out, "out")
+        if out.shape[0] != v.shape[0]:
+            raise ValueError("out: batch mismatch")
         _lib.check(self._lib.dad3d_mesh_get_normal(self._handle, out.data_ptr(), v.data_ptr(), v.shape[0],
                                                    _lib.NORMAL_ACCUMULATE if accumulate else 0, self._stream()))
         return out
 
     def get_tri_normal(self, vertices: Tensor, norm_flg: bool = False) -> Tensor:
-        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        v = self._verts(vertices)
         out = torch.empty((v.shape[0], self.ntri, 3), dtype=torch.float32, device=v.device)
         _lib.check(self._lib.dad3d_mesh_get_tri_normal(self._handle, out.data_ptr(), v.data_ptr(), v.shape[0], int(norm_flg), self._stream()))
         return out
 
     def get_ver_normal(self, tri_normal: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
         t = _chk(tri_normal, torch.float32, 3, "tri_normal", self.torch_device)
+        if tuple(t.shape[1:]) != (self.ntri, 3):
+            raise ValueError(f"tri_normal: expected [B, {self.ntri}, 3], got {tuple(t.shape)}")
+        if out is not None and (self._verts(out, "out").shape[0] != t.shape[0]):
+            raise ValueError("out: batch mismatch")
         if out is None:
             out = torch.empty((t.shape[0], self.nver, 3), dtype=torch.float32, device=t.device)
         _lib.check(self._lib.dad3d_mesh_get_ver_normal(self._handle, out.data_ptr(), t.data_ptr(), t.shape[0],
@@ -97,7 +110,7 @@ class Mesh:
         return img
 
     def rasterize_triangles(self, vertices: Tensor, h: int, w: int, depth: Optional[Tensor] = None):
-        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        v = self._verts(vertices)
         b = v.shape[0]
         if depth is None:
             depth = torch.full((b, h, w), -1e8, dtype=torch.float32, device=v.device)
@@ -114,17 +127,21 @@ class Mesh:
                     view_pos: Sequence[float] = (0, 0, 5), normals_out: Optional[Tensor] = None) -> Tensor:
         """Per-vertex Phong light (lighting.py:41-62). `normals=None`: the vertex normals are computed in the same
         launch (and stored into `normals_out` when given) -- RenderPipeline's `_get_normal` + lighting in one pass."""
-        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        v = self._verts(vertices)
         cfg = _lib.LightC(float(ambient), float(directional), float(specular), float(specular_exp),
                           (C.c_float * 3)(*color_ambient), (C.c_float * 3)(*color_directional),
                           (C.c_float * 3)(*light_pos), (C.c_float * 3)(*view_pos))
         out = torch.empty_like(v)
         if normals is None:
-            n_out = None if normals_out is None else _chk(normals_out, torch.float32, 3, "normals_out", self.torch_device)
+            n_out = None if normals_out is None else self._verts(normals_out, "normals_out")
+            if n_out is not None and n_out.shape[0] != v.shape[0]:
+                raise ValueError("normals_out: batch mismatch")
             _lib.check(self._lib.dad3d_mesh_normal_phong_light(self._handle, out.data_ptr(), None if n_out is None else n_out.data_ptr(),
                                                                v.data_ptr(), v.shape[0], C.byref(cfg), self._stream()))
             return out
-        n = _chk(normals, torch.float32, 3, "normals", self.torch_device)
+        n = self._verts(normals, "normals")
+        if n.shape[0] != v.shape[0]:
+            raise ValueError("normals: batch mismatch")
         _lib.check(self._lib.dad3d_mesh_phong_light(self._handle, out.data_ptr(), v.data_ptr(), n.data_ptr(), v.shape[0],
                                                     C.byref(cfg), self._stream()))
         return out
@@ -136,11 +153,17 @@ class Mesh:
         """RenderPipeline.__call__ (lighting.py:37-71, texture=None) for a batch in TWO launches: the raster's geometry
         kernel also computes normals + Phong light (into `light_out`, allocated when None), the tile kernel rasterises
         with it into the 3-channel `bg`. Same results as `phong_light(v, None)` followed by `rasterize`."""
-        v = _chk(vertices, torch.float32, 3, "vertices", self.torch_device)
+        v = self._verts(vertices)
         img = _chk(bg, torch.uint8, 4, "bg", self.torch_device)
         if img.shape[-1] != 3:
             raise ValueError("render needs a 3-channel image (the light has three components)")
-        light = torch.empty_like(v) if light_out is None else _chk(light_out, torch.float32, 3, "light_out", self.torch_device)
+        if img.shape[0] != v.shape[0]:
+            raise ValueError("bg: batch mismatch")
+        light = torch.empty_like(v) if light_out is None else self._verts(light_out, "light_out")
+        if light.shape[0] != v.shape[0]:
+            raise ValueError("light_out: batch mismatch")
+        if depth is not None and tuple(depth.shape) != tuple(img.shape[:3]):
+            raise ValueError("depth: expected [B, h, w] like bg")
         cfg = _lib.LightC(float(ambient), float(directional), float(specular), float(specular_exp),
                           (C.c_float * 3)(*color_ambient), (C.c_float * 3)(*color_directional),
                           (C.c_float * 3)(*light_pos), (C.c_float * 3)(*view_pos))

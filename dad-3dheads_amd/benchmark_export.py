@@ -18,13 +18,14 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from .synthetic import static_fixture_path
+from .synthetic import assets_dir
 
 SEVEN_OF_68 = (36, 39, 42, 45, 33, 48, 54)  # get_7_landmarks_from_68's default (utils.py:145)
 
 
 def embedding_path() -> str:
-    return os.path.join(os.path.dirname(static_fixture_path()), "lmk68_embedding.npz")
+    """Packaged copy of the 68-landmark barycentric embedding (`face_idx`, `b_coords`); `DAD3D_LMK68_NPZ` overrides."""
+    return os.environ.get("DAD3D_LMK68_NPZ") or os.path.join(assets_dir(), "lmk68_embedding.npz")
 
 
 class Landmarks68:

@@ -136,7 +136,11 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
 
     // Only the jaw can rotate when neck and eyeballs are size-0 inputs: their Rodrigues matrix is exactly
     // I, so 27 of the 36 pose features are exactly 0 and their basis rows can be skipped (same result).
-    const bool jaw_only = (c->neck == 0 && c->eyeballs == 0);
+    // ... and the jaw-only epilogue (S = w0+w1+w3+w4 for "the joints that cannot rotate") also needs no joint to hang
+    // off the jaw: a kinematic tree with a child of joint 2 takes the generic 36-feature path.
+    bool jaw_is_leaf = true;
+    for (int j = 1; j < kNumJoints; ++j) jaw_is_leaf = jaw_is_leaf && m->parents[j] != 2;
+    const bool jaw_only = (c->neck == 0 && c->eyeballs == 0 && jaw_is_leaf);
     h->n_pose_feats = jaw_only ? 9 : 36;
     h->pose_feat_first = jaw_only ? 9 : 0;
     const int k_used = h->n_betas + h->n_pose_feats + 1;  // [betas | pose feature | template]

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -32,6 +33,20 @@ void set_error(const char* fmt, ...);
             return DAD3D_E_INVALID;         \
         }                                   \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of a kernel ON ONE DEVICE: a launcher remembers per
+// device whether it has raised the limit there (a process-wide flag let a second device launch a 150 KB-LDS kernel
+// without the attribute). The launchers run with the handle's device current (DeviceGuard in the C ABI).
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask[4] = {};  // 256 devices
+    static int current() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 255;
+    }
+    bool done(int d) const { return (mask[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1ull; }
+    void set(int d) { mask[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release); }
+};
 
 // RAII: make `device` current for the scope of a C-ABI call, restore afterwards.
 struct DeviceGuard {

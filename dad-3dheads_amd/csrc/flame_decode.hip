@@ -856,12 +856,13 @@ size_t flame_decode_lds_bytes(int kgroups) {
 
 template <int KG, bool JAW_ONLY, bool CONTIG, bool DEV_EPOCH, int RB, bool POSED = false>
 static dad3d_status launch_decode_r(const DecodeArgs& a, hipStream_t s) {
-    static bool attr_done = false;
+    static PerDeviceOnce attr_done;
+    const int dev = PerDeviceOnce::current();
     const size_t lds = flame_decode_lds_bytes(KG);
-    if (!attr_done) {
+    if (!attr_done.done(dev)) {
         DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB, POSED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.set(dev);
     }
     const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8 * a.nbb;
     hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB, POSED>), dim3(grid), dim3(512), lds, s, a);

@@ -984,11 +984,12 @@ dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float*
     if (m.nver == 0 || batch == 0) return DAD3D_OK;
     const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
     if (lds <= kMaxDynamicLds) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceOnce attr_done;
+        const int dev = PerDeviceOnce::current();
+        if (!attr_done.done(dev)) {
             DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ver_normal_lds_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds));
-            attr_done = true;
+            attr_done.set(dev);
         }
         const int vpb = staged_verts_per_block(m.nver, batch);
         hipLaunchKernelGGL(ver_normal_lds_kernel, dim3((m.nver + vpb - 1) / vpb, batch), dim3(kStageThreads), lds, s, m,
@@ -1039,9 +1040,11 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
                   w, kMaxTiles, kTile, kTile);
     DAD3D_REQUIRE((unsigned)m.ntri <= kIdMask, "rasterize: more than 2^28 triangles");
     DAD3D_REQUIRE(scratch, "rasterize: no scratch buffer");
-    static int persistent_blocks[2] = {0, 0};
+    static int persistent_blocks[2] = {0, 0};           // the same for every device of the node (one GPU model)
+    static PerDeviceOnce raster_attr_done;              // the LDS limit is raised per device
+    const int cur_dev = PerDeviceOnce::current();
     constexpr int kMaxLds = 160 * 1024 - 1024;  // dynamic part: the geometry kernel also has some static words
-    if (!persistent_blocks[0]) {
+    if (!raster_attr_done.done(cur_dev)) {
         DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, true>),
@@ -1053,6 +1056,7 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
         DAD3D_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], raster_kernel<1>, kRasterThreads, 0));
         persistent_blocks[1] = std::max(1, cus * per_cu[1]);
         persistent_blocks[0] = std::max(1, cus * per_cu[0]);
+        raster_attr_done.set(cur_dev);
     }
     const ScratchLayout lay(m, batch, h, w);
     char* base = static_cast<char*>(scratch);
@@ -1093,13 +1097,14 @@ dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices,
     if (batch == 0 || m.nver == 0) return DAD3D_OK;
     const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
     DAD3D_REQUIRE(lds <= kMaxDynamicLds - 1024, "phong_light: %d vertices exceed the LDS staging capacity", m.nver);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    const int dev = PerDeviceOnce::current();
+    if (!attr_done.done(dev)) {
         DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
         DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
-        attr_done = true;
+        attr_done.set(dev);
     }
     const int vpb = staged_verts_per_block(m.nver, batch);
     const dim3 grid((m.nver + vpb - 1) / vpb, batch);

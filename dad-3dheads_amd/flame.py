@@ -231,7 +231,12 @@ class FLAMELayer(torch.nn.Module):
         dev = params.device
 
         def buf(key, shape, dtype=torch.float32):
+            # a tensor left in `out` by an earlier call is reused only if the kernel can write all of this call's
+            # rows into it: same shape, dtype, device, contiguous -- anything else would be written out of bounds
             t = res.get(key)
+            if t is not None and (tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev or not t.is_contiguous()):
+                raise ValueError(f"out[{key!r}]: expected a contiguous {dtype} tensor {tuple(shape)} on {dev}, "
+                                 f"got {t.dtype} {tuple(t.shape)} on {t.device}")
             if t is None:
                 t = torch.empty(shape, dtype=dtype, device=dev)
                 res[key] = t

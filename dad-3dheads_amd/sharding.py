@@ -70,7 +70,10 @@ class ShardedLandmarkDecoder:
         dev = self.head_mesh.flame.torch_device
         mine = params_global[lo:hi].to(dev, torch.float32).contiguous()
         if hi > lo:
-            px = self.head_mesh.decode(mine, verts3d=False, proj=False, landmarks=False, landmarks_px=True)["lmk_px"]
+            # mutate=False: `mine` may be a view of the caller's tensor, and a landmark decode has no business zeroing
+            # translation z in this rank's rows of it (head_mesh.py:41 is reprojected_vertices' side effect)
+            px = self.head_mesh.decode(mine, verts3d=False, proj=False, landmarks=False, landmarks_px=True,
+                                       mutate=False)["lmk_px"]
         else:
             px = torch.empty((0, self.head_mesh.flame.n_landmarks, 2), dtype=torch.int32, device=dev)
         return gather_rows(px, n, self.group)

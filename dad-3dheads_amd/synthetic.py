@@ -28,12 +28,15 @@ N_PARAMS = 413  # shape300 | expr100 | jaw3 | rot6d 6 | trans3 | scale1  (flame.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def assets_dir() -> str:
+    """Package data: the static index assets of the FLAME topology (dad-3dheads_amd/assets/, see its NOTICE.md)."""
+    return os.path.join(_HERE, "assets")
+
+
 def static_fixture_path() -> str:
-    """Where the frozen static assets live (see tests/golden/make_static_fixture.py)."""
-    env = os.environ.get("DAD3D_STATIC_NPZ")
-    if env:
-        return env
-    return os.path.join(os.path.dirname(_HERE), "tests", "golden", "flame_static.npz")
+    """The frozen static assets (face list, face subset, landmark index lists; built by
+    tests/golden/make_static_fixture.py from a reference checkout). `DAD3D_STATIC_NPZ` overrides the packaged copy."""
+    return os.environ.get("DAD3D_STATIC_NPZ") or os.path.join(assets_dir(), "flame_static.npz")
 
 
 def load_static(path: Optional[str] = None) -> dict:

@@ -68,6 +68,9 @@ def main():
     lmk = torch.stack([ref_utils.get_68_landmarks(v) for v in verts])
     seven = np.stack([ref_utils.get_7_landmarks_from_68(l) for l in lmk])
     np.savez_compressed(OUT, face_idx=face_idx, b_coords=b_coords, verts=verts.numpy(), lmk68=lmk.numpy(), lmk7=seven)
+    if len(sys.argv) <= 1:  # the embedding alone is package data (dad-3dheads_amd/assets/), the goldens stay here
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(OUT))))
+        np.savez_compressed(os.path.join(root, "dad-3dheads_amd", "assets", "lmk68_embedding.npz"), face_idx=face_idx, b_coords=b_coords)
     print("wrote", OUT, os.path.getsize(OUT), "bytes; lmk68", lmk.shape, "lmk7", seven.shape)
 
 

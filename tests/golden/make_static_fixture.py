@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build tests/golden/flame_static.npz from the reference's static assets.
+"""Build dad-3dheads_amd/assets/flame_static.npz (package data) from the reference's static assets.
 
 Runs ONLY in the authoring container (needs /root/reference). The GPU box has no
 /root/reference, so everything the tests / bench / smoke need from
@@ -32,7 +32,7 @@ import torch
 
 REF = os.environ.get("DAD3D_REFERENCE_ROOT", "/root/reference")
 STATIC = os.path.join(REF, "model_training/model/static")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "flame_static.npz")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "dad-3dheads_amd", "assets", "flame_static.npz")
 
 
 def load_indices_from_npy(path):
