@@ -1,36 +1,45 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of FLAME decode + 445-landmark projection, batch 64 @ 256^2 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 re-launches itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of 64 synthetic parameter rows per GPU, already
-resident in HBM: prologue kernel + fused blend-shape/skinning/projection kernel producing, per image,
+resident in HBM: ONE fused launch (pose role + blend-shape GEMM / skinning / projection role) producing, per image,
 `3d_vertices [5023,3]`, `projected_vertices [5023,2]` and the 445 integer landmarks -- everything
 `FaceMeshPredictor` + `draw_3d_landmarks` derive from one params row (predictor.py:136-137,
 demo_utils.py:42-46; the reference decodes twice, this path once). BASELINE.json configs[1].
 
-Default (`--streams 1`, the contract line): every step is launched on one HIP stream; two hipEvents on that stream
-bracket the K launches of the timed region, and `roofline.achieved` = algorithmic flops per launch / (event time / K) --
-the number `rocprofv3 --kernel-trace --stats` of the same command reports as the kernel's average duration
-(profiles/r01_bench_kernel_stats.csv).
+Timing. An untimed, disclosed clock-ramp phase (launches until `--prewarm-ms` have passed, default 50; reported as
+`config.prewarm_ms`) precedes the W counted warm-up steps: the driver runs `--steps 20 --warmup 5`, and 25 launches after a
+cold start measure the power state, not the kernel. The K timed steps sit between barrier + synchronize on both sides
+(`wall_ms_per_step`, MAX over ranks). With one stream per rank (the contract line) two hipEvents on the launch stream
+bracket exactly the K launches; `value` and `ms_per_step` are taken from them (MAX over ranks) -- the wall clock around a
+0.3 ms region adds the host's launch latency and the final synchronize (~2 us per step at K = 20) to a 13 us step. Both
+are printed; `config.value_from` says which one `value` is. `roofline.achieved` = algorithmic flops per launch / (event
+time / K), the number `rocprofv3 --kernel-trace --stats` of the same command reports as the kernel's average duration.
 
-`--streams S` issues the steps round-robin on S HIP streams, each with its own fork of the decode handle (model
-constants shared in HBM) and its own params / output buffers: a serving loop with S batches of 64 in flight, which
-hides the launch gap and the start-up / epilogue tails of one launch behind the GEMM of another (5.27 M img/s with
-S = 2, +12 %; no further gain with 3..6). Kernels of different streams then overlap, so the kernel
-duration for the roofline object is taken from one more pass of K launches on ONE stream.
+`--streams S` issues the steps round-robin on S HIP streams (S batches of 64 in flight per GPU; kernels of different
+streams overlap, so `value` is the wall clock and the kernel duration for the roofline object comes from one more pass of K
+launches on ONE stream).
 
 Multi-GPU: images shard over ranks (weak scaling, 64 per GPU per step, no data-path collective); the timed
 region ends with the job's single RCCL all-gather of the last step's landmarks (north_star: "RCCL/xGMI
-only for the final gather"). Rank 0 prints ONE JSON line.
+only for the final gather"); with N > 1 `value` is the wall clock (the gather runs on RCCL's stream). Rank 0 prints ONE
+JSON line.
+
+`--workload render` (BASELINE configs[4], not the headline metric): per step and GPU 64 images of head_mesh decode ->
+vertex normals + Phong light -> z-buffer raster of the 9976-triangle mesh onto 256 x 256 x 3 (three launches), the timed
+region ends with one all-gather of the uint8 images of the last step.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -40,17 +49,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from dad_3dheads_amd import _lib, landmarks, synthetic  # noqa: E402
-from dad_3dheads_amd.head_mesh import HeadMesh  # noqa: E402
-
 BATCH = 64
 N_VERTS, N_LMK, N_PARAMS = 5023, 445, 413
 # algorithmic work of ONE fused decode
 FLOP_PER_IMAGE = 14.5e6
 CONST_BYTES = 26_541_532  # basis + template + weights + regressor, read once per launch
 BYTES_PER_IMAGE = 105_672  # params 1652 + verts3d 60276 + proj2d 40184 + landmarks 3560
+RASTER_BYTES_PER_IMAGE = 513_768  # rasterize; + 120 552 for the normals
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+GOLDEN_SEED = 102  # tests/golden/decode_golden.npz "b64": rank 0 / stream 0 decodes exactly these rows
 
 
 def cpu_baseline(model, lmk_idx, budget_s: float = 15.0):
@@ -60,6 +68,7 @@ def cpu_baseline(model, lmk_idx, budget_s: float = 15.0):
     thread count; on a many-core host torch's default (= all cores) is pathologically slow for these small
     ops, so a few thread counts are tried inside the time budget and the FASTEST is reported (`cores` = the
     threads it used) -- the most generous reading of the baseline."""
+    from dad_3dheads_amd import synthetic
     from oracle import flame_ref
 
     consts = flame_ref.FlameConstants.from_model(model)
@@ -91,26 +100,54 @@ def cpu_baseline(model, lmk_idx, budget_s: float = 15.0):
     }
 
 
-def pmc_traffic_bytes():
-    """HBM-side bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/*pmc*.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs, KB units, FETCH doubled per MI355X_MICROARCH.md). PMC
-    cannot be collected inside this process; null when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
-    except Exception:
-        return None
+def cpu_baseline_render(verts0, faces, budget_s: float = 10.0):
+    """RenderPipeline of the reference on one host core (the reference's own Sim3DR C++ when oracle/_ref holds it,
+    else the C port), one image per call like demo_utils.py:152-170."""
+    from oracle import sim3dr_ref
+
+    kind = "reference" if sim3dr_ref.available("reference") else "port"
+    orc = sim3dr_ref.Sim3DROracle(kind)
+    fn = lambda: sim3dr_ref.render_pipeline_ref(orc, verts0.copy(), faces, np.zeros((256, 256, 3), np.uint8))  # noqa: E731
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        fn()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/sec", "cores": 1, "kind": kind,
+            "sample": f"{n} images in {dt:.1f} s: RenderPipeline (_get_normal + numpy Phong light + _rasterize) of one decoded mesh "
+                      f"per call, Sim3DR C++ ({kind}) on one host core"}
 
 
-def pmc_mfma_busy():
-    """Fraction of the kernel's duration the MFMA pipes were busy, all SIMDs (SQ_VALU_MFMA_BUSY_CYCLES from the committed
-    rocprofv3 pass, profiles/r01_pmc_sq.json); null when absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")) as f:
-            return json.load(f)["mfma_busy_fraction_of_kernel_time_all_1024_simds"]
-    except Exception:
-        return None
+def pmc_json(name, key):
+    """A per-launch figure of the fused kernel from the committed rocprofv3 PMC passes (profiles/: FETCH_SIZE and WRITE_SIZE
+    collected in separate runs, KB units, FETCH doubled per MI355X_MICROARCH.md; SQ_VALU_MFMA_BUSY_CYCLES). PMC cannot be
+    collected inside this process: these are CONSTANTS READ FROM COMMITTED FILES (the file is named next to them), null when
+    absent."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
+                return json.load(f)[key], f"profiles/{rnd}_{name}.json"
+        except Exception:
+            continue
+    return None, None
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`."""
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < args.gpus:
+        raise SystemExit(f"bench.py: {args.gpus} GPUs requested, {visible} visible on this node -- nothing was run "
+                         f"(one rank per GPU; launch on a node with at least {args.gpus} MI355X)")
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main() -> None:
@@ -119,36 +156,106 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the steps are issued on, round-robin")
+    ap.add_argument("--prewarm-ms", type=float, default=50.0, help="untimed clock-ramp phase before the counted warm-up")
+    ap.add_argument("--workload", choices=("decode", "render"), default="decode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        self_launch(args)  # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # under torch.distributed.run, even N=1
+    if under_launcher:  # under torch.distributed.run, even N = 1: the RCCL path is the one that is timed
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+
+    from dad_3dheads_amd import _lib, landmarks, synthetic
+    from dad_3dheads_amd.head_mesh import HeadMesh
 
     static = synthetic.load_static()
     model = synthetic.synthetic_flame_model(0, static)
     lmk_idx = landmarks.canonical("445", static)
     hm = HeadMesh(flame_model=model, landmarks=lmk_idx, static=static, device=local_rank)
     lib = _lib.load()
+    run = run_render if args.workload == "render" else run_decode
+    out = run(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def fence(dist, dev):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+
+def prewarm(step, ms: float, dev) -> float:
+    """Untimed: issue steps until `ms` of wall clock have passed (clock ramp, instruction caches, RCCL-free)."""
+    t0, k = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(16):
+            step(k)
+            k += 1
+        torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3
+
+
+def max_over_ranks(dist, dev, x: float) -> float:
+    if dist is None:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def verify_against_golden(sets0, lmk_idx, dev):
+    """The buffers the TIMED launches wrote (rank 0, stream 0: params = the golden's own rows) against
+    tests/golden/decode_golden.npz -- outputs of the reference's own HeadMesh on the same seeded model: a fixed subset of
+    128 vertices (3-D within 5e-6, projection within 1e-3 px) and the 445 integer landmarks (equal; a pixel may differ by
+    one only where the reference's float coordinate is within 1e-3 of an integer)."""
+    path = os.path.join(ROOT, "tests", "golden", "decode_golden.npz")
+    try:
+        g = np.load(path)
+    except Exception as e:  # a checkout without tests/: say so instead of claiming a check
+        return {"checked": False, "why": f"{type(e).__name__}: {e}"}
+    sub = g["b64_subset"]
+    dv = float(np.abs(sets0["verts3d"].cpu().numpy()[:, sub] - g["b64_v3d_sub"]).max())
+    dp = float(np.abs(sets0["proj"].cpu().numpy()[:, sub] - g["b64_proj_sub"]).max())
+    diff = sets0["lmk_px"].cpu().numpy() != g["b64_lmk_px"]
+    near_int = np.abs(g["b64_lmk_xy"] - np.round(g["b64_lmk_xy"])) < 1e-3
+    idx_dev = torch.from_numpy(lmk_idx).to(dev)
+    gather_exact = bool(torch.equal(sets0["lmk_px"], sets0["proj"][:, idx_dev, :].to(torch.int32)))
+    ok = dv < 5e-6 and dp < 1e-3 and bool(near_int[diff].all()) and gather_exact
+    return {"checked": True, "ok": bool(ok), "max_abs_3d": dv, "max_abs_px": dp, "landmark_px_differ": int(diff.sum()),
+            "landmark_gather_exact": gather_exact, "golden": "tests/golden/decode_golden.npz b64_* (reference HeadMesh, seed 102)"}
+
+
+def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
+    from dad_3dheads_amd import _lib, synthetic
+
     n_streams = max(1, args.streams)
     meshes = [hm] + [hm.fork() for _ in range(n_streams - 1)]  # one handle per stream, constants shared in HBM
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     flags = _lib.TO_2D | _lib.MUTATE_PARAMS
     sets = []
     for i in range(n_streams):  # per-rank seed = base + rank (SURVEY 8d); further streams continue the sequence
-        params = torch.from_numpy(synthetic.synthetic_params(BATCH, seed=rank + world * i)).to(dev)
+        params = torch.from_numpy(synthetic.synthetic_params(BATCH, seed=GOLDEN_SEED + rank + world * i)).to(dev)
         verts3d = torch.empty((BATCH, N_VERTS, 3), dtype=torch.float32, device=dev)
         proj = torch.empty((BATCH, N_VERTS, 2), dtype=torch.float32, device=dev)
         lmk_px = torch.empty((BATCH, N_LMK, 2), dtype=torch.int32, device=dev)
@@ -168,20 +275,15 @@ def main() -> None:
         torch.cuda.current_stream(dev).wait_stream(streams[k_last % n_streams])
         dist.all_gather_into_tensor(gathered, sets[k_last % n_streams]["lmk_px"])
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
+    prewarm_ms = prewarm(step, args.prewarm_ms, dev)
     for k in range(args.warmup):
         step(k)
     if dist is not None:
         gather_last(max(args.warmup - 1, 0))  # RCCL communicator warm-up (untimed)
-    import ctypes as C
 
     handle, stream = sets[0]["call"][0], sets[0]["call"][-1]
     tot, cnt = C.c_double(), C.c_int()
-    fence()
+    fence(dist, dev)
     t0 = time.perf_counter()
     if n_streams == 1:  # two hipEvents on the launch stream bracket the K launches of the timed region itself
         _lib.check(lib.dad3d_flame_profile_begin(handle, stream))
@@ -191,12 +293,8 @@ def main() -> None:
         _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     if dist is not None:
         gather_last(args.steps - 1)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    fence(dist, dev)
+    wall = max_over_ranks(dist, dev, time.perf_counter() - t0)
 
     # dominant-kernel duration = hipEvent time of the K back-to-back launches / K (one kernel per step). With one
     # stream the events bracketed the timed region; with several, kernels of different streams overlap and a launch's
@@ -209,66 +307,145 @@ def main() -> None:
                 _lib.check(st)
         _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     kern_s = tot.value / max(cnt.value, 1) * 1e-3
+    events_s = max_over_ranks(dist, dev, tot.value * 1e-3)  # this rank's K launches on its stream, MAX over ranks
 
-    # sanity: the timed path produced the oracle's answer (cheap spot check on rank 0, outside the timed region)
-    idx_dev = torch.from_numpy(lmk_idx).to(dev)
-    ok = all(bool(torch.equal(s_["lmk_px"], s_["proj"][:, idx_dev, :].to(torch.int32))) for s_ in sets)
-
+    timeouts = C.c_uint()
+    _lib.check(lib.dad3d_flame_handoff_timeouts(handle, C.byref(timeouts)))
+    check = verify_against_golden(sets[0], lmk_idx, dev) if rank == 0 else None
+    ok_gather = True
     if dist is not None:  # this rank's slice of the gathered landmarks is what its last timed step wrote
         mine = sets[(args.steps - 1) % n_streams]["lmk_px"]
-        ok = ok and bool(torch.equal(gathered[rank * BATCH:(rank + 1) * BATCH], mine))
-    if rank == 0:
-        images = world * BATCH * args.steps
-        flops = FLOP_PER_IMAGE * BATCH
-        alg_bytes = CONST_BYTES + BATCH * BYTES_PER_IMAGE
-        out = {
-            "metric": "images/sec (FLAME decode + 445-lmk projection), batch 64 @ 256^2",
-            "value": images / elapsed,
-            "unit": "images/sec",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[1]: batch=64 synthetic 256x256 per GPU, 445_landmarks path "
-                            "(3d_vertices + projected_vertices + 445 int landmarks per image), seeded synthetic "
-                            "FLAME-shaped model (real flame.pkl not redistributed)",
-                "batch_per_gpu": BATCH,
-                "global_batch": world * BATCH,
-                "parallelism": f"image-sharded x{world}, one final RCCL all-gather of landmarks",
-                "streams": n_streams,
-                "single_stream_ms_per_step": kern_s * 1e3,
-                "outputs_verified": ok,
-            },
-            "roofline": {
-                "kernel": "flame_decode_kernel<26,true,true> (pose role + decode role, one launch per step); duration = "
-                          "back-to-back launches on ONE stream",
-                "bound": "mfma",
-                "achieved": flops / kern_s / 1e12,
-                "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": flops / kern_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc_traffic_bytes(),
-                "mfma_busy_pmc": pmc_mfma_busy(),
-                "kernel_us": kern_s * 1e6,
-                "algorithmic_flop_per_launch": flops,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "hbm_equiv_GBps": alg_bytes / kern_s / 1e9,
-                "hbm_frac": alg_bytes / kern_s / 1e9 / PEAK_HBM_GBS,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, lmk_idx)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        ok_gather = bool(torch.equal(gathered[rank * BATCH:(rank + 1) * BATCH], mine))
+    if rank != 0:
+        return None
+    images = world * BATCH * args.steps
+    flops = FLOP_PER_IMAGE * BATCH
+    alg_bytes = CONST_BYTES + BATCH * BYTES_PER_IMAGE
+    from_events = n_streams == 1 and world == 1  # one stream, no collective inside the region: the events ARE the K steps
+    elapsed = events_s if from_events else wall
+    traffic, traffic_src = pmc_json("pmc_traffic", "traffic_bytes_per_launch")
+    mfma_busy, mfma_src = pmc_json("pmc_sq", "mfma_busy_fraction_of_kernel_time_all_1024_simds")
+    out = {
+        "metric": "images/sec (FLAME decode + 445-lmk projection), batch 64 @ 256^2",
+        "value": images / elapsed,
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "wall_ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: batch=64 synthetic 256x256 per GPU, 445_landmarks path "
+                        "(3d_vertices + projected_vertices + 445 int landmarks per image), seeded synthetic "
+                        "FLAME-shaped model (real flame.pkl not redistributed)",
+            "batch_per_gpu": BATCH,
+            "global_batch": world * BATCH,
+            "parallelism": f"image-sharded x{world}, one final RCCL all-gather of landmarks"
+                           + (" (process group: nccl)" if dist is not None else " (no process group: plain N=1 run)"),
+            "streams": n_streams,
+            "prewarm_ms": prewarm_ms,
+            "value_from": "hipEvents on the launch stream around the K timed launches (MAX over ranks)" if from_events
+                          else "wall clock between barrier+synchronize pairs (MAX over ranks)",
+            "images_per_sec_wall": images / wall,
+            "single_stream_ms_per_step": kern_s * 1e3,
+            "outputs_verified": bool(check.get("ok")) and ok_gather if check and check.get("checked") else None,
+            "verification": check,
+            "handoff_timeouts": int(timeouts.value),
+        },
+        "roofline": {
+            "kernel": "flame_decode_kernel<26,true,true> (pose role + decode role, one launch per step); duration = "
+                      "back-to-back launches on ONE stream",
+            "bound": "mfma",
+            "achieved": flops / kern_s / 1e12,
+            "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": flops / kern_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic,
+            "traffic_source": traffic_src and traffic_src + " (committed PMC pass, NOT measured in this run)",
+            "mfma_busy_pmc": mfma_busy,
+            "mfma_busy_source": mfma_src and mfma_src + " (committed PMC pass, NOT measured in this run)",
+            "kernel_us": kern_s * 1e6,
+            "algorithmic_flop_per_launch": flops,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "hbm_equiv_GBps": alg_bytes / kern_s / 1e9,
+            "hbm_frac": alg_bytes / kern_s / 1e9 / PEAK_HBM_GBS,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, lmk_idx)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def run_render(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
+    """BASELINE configs[4] per-GPU share: decode (3-component projection, z flipped) -> normals + Phong + raster."""
+    from dad_3dheads_amd import synthetic
+    from dad_3dheads_amd.Sim3DR import Mesh
+    from dad_3dheads_amd.sharding import ShardedRenderer
+
+    faces = static["faces"]
+    mesh = Mesh(faces, N_VERTS, device=dev.index)
+    renderer = ShardedRenderer(hm, mesh)
+    params = torch.from_numpy(synthetic.synthetic_params(BATCH, seed=GOLDEN_SEED + rank)).to(dev)
+    gathered = torch.empty((world * BATCH, 256, 256, 3), dtype=torch.uint8, device=dev) if dist is not None else None
+    torch.cuda.synchronize(dev)
+    step = lambda k: renderer.render_local(params)  # noqa: E731
+
+    def gather_last():
+        dist.all_gather_into_tensor(gathered, renderer._img)  # the images the last step rendered (same stream: ordered)
+
+    prewarm_ms = prewarm(step, args.prewarm_ms, dev)
+    for k in range(args.warmup):
+        step(k)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        gather_last()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence(dist, dev)
+    t0 = time.perf_counter()
+    e0.record()
+    for k in range(args.steps):
+        step(k)
+    e1.record()
+    if dist is not None:
+        gather_last()
+    fence(dist, dev)
+    wall = max_over_ranks(dist, dev, time.perf_counter() - t0)
+    ev_s = max_over_ranks(dist, dev, e0.elapsed_time(e1) * 1e-3)
+    if rank != 0:
+        return None
+    img = renderer._img
+    covered = float((img.reshape(BATCH, -1).max(dim=1).values > 0).float().mean().item())
+    ok_gather = True if dist is None else bool(torch.equal(gathered[:BATCH], img))
+    images = world * BATCH * args.steps
+    elapsed = ev_s if world == 1 else wall
+    alg = BATCH * (RASTER_BYTES_PER_IMAGE + 120_552) + CONST_BYTES + BATCH * (1652 + 60_276)
+    out = {
+        "metric": "images/sec (head_mesh decode + Sim3DR face-mesh render), batch 64 @ 256^2 per GPU",
+        "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "wall_ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] per-GPU share: batch=64 head_mesh (3-component projection) + vertex normals + "
+                               "Phong light + z-buffer raster of 9976 triangles onto 256x256x3 uint8, three launches per step; "
+                               "one all-gather of the uint8 images ends the job",
+                   "batch_per_gpu": BATCH, "global_batch": world * BATCH,
+                   "parallelism": f"image-sharded x{world}, one final RCCL all-gather of [64,256,256,3] uint8 per rank",
+                   "prewarm_ms": prewarm_ms, "images_with_coverage": covered, "gather_verified": ok_gather,
+                   "value_from": "torch events around the K timed steps" if world == 1 else "wall clock (MAX over ranks)"},
+        "roofline": {"kernel": "decode + tri_geometry(+normals+light) + raster_kernel, three launches", "bound": "hbm",
+                     "achieved": alg / (ev_s / args.steps) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": alg / (ev_s / args.steps) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                     "algorithmic_bytes_per_step": alg},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        verts0 = np.ascontiguousarray(renderer._dec["proj"][0].cpu().numpy())
+        out["cpu_baseline"] = cpu_baseline_render(verts0, faces)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 if __name__ == "__main__":

@@ -298,7 +298,9 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const float*
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float refl = 2.0f * cosv * n[k] - d[k];
-                spe += powf(e[k] * refl, cfg.specular_exp);
+                // np.power(float32 array, scalar): exact fast paths for 1 (copy) and 2 (square), libm / SVML powf otherwise
+                const float t = e[k] * refl;
+                spe += cfg.specular_exp == 2.0f ? t * t : cfg.specular_exp == 1.0f ? t : powf(t, cfg.specular_exp);
             }
             spe = (cosv != 0.0f) ? clip01(spe) : 0.0f;
 #pragma unroll

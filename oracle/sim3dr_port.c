@@ -157,6 +157,38 @@ void port_rasterize(unsigned char *image, const float *vertices, const int *tria
     }
 }
 
+/* TEST DIAGNOSTIC (no counterpart in the reference): port_rasterize that ALSO records, per written byte, the float it
+ * was cast from -- `(1 - alpha) * image + alpha * 255 * p_color` of rasterize_kernel.cpp:276-281 -- into
+ * `precast` [h][w][c] (untouched where nothing is drawn). tests/render_checks.py uses it to show that a byte which
+ * differs from the reference's sits on a truncation boundary. Same loop, same expressions as port_rasterize; the test
+ * suite holds its byte output to port_rasterize's. */
+void port_rasterize_precast(unsigned char *image, float *precast, const float *vertices, const int *triangles,
+                            const float *colors, float *depth_buffer, int ntri, int h, int w, int c, float alpha, int reverse) {
+    for (int t = 0; t < ntri; ++t) {
+        const int i0 = triangles[3 * t], i1 = triangles[3 * t + 1], i2 = triangles[3 * t + 2];
+        const float *p0 = vertices + 3 * i0, *p1 = vertices + 3 * i1, *p2 = vertices + 3 * i2;
+        box_t b;
+        if (!tri_box(p0, p1, p2, h, w, &b)) continue;
+        for (int y = b.y0; y <= b.y1; ++y)
+            for (int x = b.x0; x <= b.x1; ++x) {
+                float wgt[3];
+                port_point_weight(wgt, (float)x, (float)y, p0[0], p0[1], p1[0], p1[1], p2[0], p2[1]);
+                if (!(wgt[2] > 0 && wgt[1] > 0 && wgt[0] > 0)) continue;
+                float z = wgt[0] * p0[2] + wgt[1] * p1[2] + wgt[2] * p2[2];
+                if (!(z > depth_buffer[y * w + x])) continue;
+                int row = reverse ? (h - 1 - y) : y;
+                unsigned char *px = image + ((size_t)row * w + x) * c;
+                float *pf = precast + ((size_t)row * w + x) * c;
+                for (int k = 0; k < c; ++k) {
+                    float col = wgt[0] * colors[c * i0 + k] + wgt[1] * colors[c * i1 + k] + wgt[2] * colors[c * i2 + k];
+                    pf[k] = (1 - alpha) * px[k] + alpha * 255 * col;
+                    px[k] = f2u8_x86(pf[k]);
+                }
+                depth_buffer[y * w + x] = z;
+            }
+    }
+}
+
 void port_rasterize_triangles(const float *vertices, const int *triangles, float *depth_buffer, int *triangle_buffer,
                               float *barycentric_weight, int ntri, int h, int w) {
     for (int t = 0; t < ntri; ++t) {

@@ -112,6 +112,21 @@ class Sim3DROracle:
                      triangles.shape[0], height, width, channel, float(alpha), int(reverse))
         return (bg, buf) if return_depth else bg
 
+    def rasterize_precast(self, vertices, triangles, colors, height, width, channel=3, reverse=False):
+        """Port only (test diagnostic): `rasterize` onto a black image plus the float every written byte was cast from
+        (`alpha * 255 * p_color`, rasterize_kernel.cpp:276-281). Returns (image uint8, precast float32, drawn bool)."""
+        lib = self.lib if self.kind == "port" else Sim3DROracle("port").lib
+        fn = lib.port_rasterize_precast
+        fn.argtypes = [_U8, _F, _F, _I, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+        fn.restype = None
+        img = np.zeros((height, width, channel), dtype=np.uint8)
+        pre = np.full((height, width, channel), np.nan, dtype=np.float32)
+        buf = np.zeros((height, width), dtype=np.float32) - 1e8
+        colors = np.ascontiguousarray(colors, dtype=np.float32)
+        fn(img.ctypes.data_as(_U8), self._f(pre), self._f(np.ascontiguousarray(vertices, dtype=np.float32)), self._i(triangles),
+           self._f(colors), self._f(buf), triangles.shape[0], height, width, channel, 1.0, int(reverse))
+        return img, pre, ~np.isnan(pre[..., 0])
+
     def rasterize_triangles(self, vertices, triangles, h, w, depth=None):
         depth = (np.zeros((h, w), np.float32) - 1e8) if depth is None else depth
         tri_buf = np.zeros((h, w), np.int32) - 1

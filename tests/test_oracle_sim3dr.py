@@ -105,3 +105,25 @@ def test_empty_and_offscreen(port_oracle):
     # unreferenced vertices get the (0,0,0)/1e-6 normal = 0
     n = port_oracle.get_normal(np.zeros((5, 3), np.float32), np.array([[0, 1, 2]], np.int32))
     assert np.array_equal(n, np.zeros((5, 3), np.float32))
+
+
+def test_precast_diagnostic_is_the_port_raster_plus_floats(static, decode_golden, port_oracle):
+    """`port_rasterize_precast` (tests/render_checks.py builds on it) writes the same bytes as `port_rasterize` -- which is
+    pinned to the reference's C++ above -- and every byte is the x86 cast of the float it reports; the byte checker accepts
+    a light that is off by 1.5e-5 and rejects one that is off by 4e-4."""
+    from oracle.sim3dr_ref import render_pipeline_ref
+    from render_checks import assert_render_bytes_explained
+
+    faces = static["faces"]
+    v = decode_golden["b2_proj3"][0].copy()
+    v[:, 2] *= -1.0
+    ref, light = render_pipeline_ref(port_oracle, v.copy(), faces, np.zeros((256, 256, 3), np.uint8))
+    img, pre, drawn = port_oracle.rasterize_precast(v, faces, light, 256, 256, 3)
+    assert np.array_equal(img, ref) and drawn.sum() > 10000
+    assert np.array_equal(pre[drawn].astype(np.int32).astype(np.uint8), ref[drawn])  # cvttss2si, low 8 bits
+    assert assert_render_bytes_explained(ref.copy(), ref, port_oracle, v, faces, light) == 0
+    near = port_oracle.rasterize(v.copy(), faces, np.clip(light + np.float32(1.5e-5), 0, 1), bg=np.zeros((256, 256, 3), np.uint8))
+    assert 0 < assert_render_bytes_explained(near, ref, port_oracle, v, faces, light) < 500
+    far = port_oracle.rasterize(v.copy(), faces, np.clip(light + np.float32(4e-4), 0, 1), bg=np.zeros((256, 256, 3), np.uint8))
+    with pytest.raises(AssertionError):
+        assert_render_bytes_explained(far, ref, port_oracle, v, faces, light)

@@ -79,3 +79,47 @@ def test_gather_rows_single_process_passthrough():
     assert sharding.gather_rows(x, 4) is x
     with pytest.raises(ValueError):
         sharding.gather_rows(x, 5)
+
+
+def _image_worker(rank, world, port, n_list, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for n in n_list:
+            lo, hi = sharding.shard_range(n, rank, world)
+            rows = torch.arange(lo, hi, dtype=torch.int64)  # image i is filled with a pattern derived from i
+            local = ((rows[:, None, None, None] * 7 + torch.arange(3)[None, None, None, :] * 11 +
+                      torch.arange(8)[None, :, None, None] * 3 + torch.arange(6)[None, None, :, None]) % 251).to(torch.uint8)
+            full = sharding.gather_rows(local.contiguous(), n)
+            np.save(os.path.join(out_dir, f"img_r{rank}_n{n}.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_uint8_images_two_ranks(tmp_path):
+    """BASELINE config 5's collective: [n_r, h, w, 3] uint8 images per rank -> the whole batch on every rank."""
+    n_list, world = [6, 5], 2
+    mp.spawn(_image_worker, args=(world, _free_port(), n_list, str(tmp_path)), nprocs=world, join=True)
+    for n in n_list:
+        rows = np.arange(n)[:, None, None, None]
+        ref = ((rows * 7 + np.arange(3)[None, None, None, :] * 11 + np.arange(8)[None, :, None, None] * 3 +
+                np.arange(6)[None, None, :, None]) % 251).astype(np.uint8)
+        for r in range(world):
+            got = np.load(tmp_path / f"img_r{r}_n{n}.npy")
+            assert got.dtype == np.uint8 and np.array_equal(got, ref), (n, r)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` is what the driver runs: with fewer devices than N it must say so (not print a usage
+    error, not hang in a rendezvous). This container has no GPU at all, so N = 2 is refused the same way."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the refusal path is not reachable here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "2 GPUs requested" in p.stderr and "visible" in p.stderr, p.stderr[-500:]
