@@ -166,6 +166,42 @@ def test_obj_and_json_writers_produce_the_reference_bytes(tmp_path):
     assert writers.get_output_path("/x/y/1.jpeg", "out", "head_mesh", ".obj") == "out/1_head_mesh.obj"
 
 
+def test_writers_reproduce_the_bytes_of_the_reference_demo_utils(tmp_path, static, flame_consts):
+    """writers.py vs the reference's OWN `demo_utils.py` (MeshSaver / JsonSaver / get_mesh / get_flame_params /
+    get_output_path run unmodified by tests/golden/make_writers_golden.py): byte-identical .obj and .json files for seeded
+    decodes, single and batch entry points."""
+    import torch
+
+    from dad_3dheads_amd import synthetic, writers
+    from oracle import flame_ref
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "writers_golden.npz")) as g:
+        g = {k: g[k] for k in g.files}
+    batch, seed = int(g["batch"]), int(g["seed"])
+    params = torch.from_numpy(synthetic.synthetic_params(batch, seed=seed))
+    verts = flame_ref.vertices_3d(flame_consts, params.clone())
+    assert bool(g["faces_equal_static"]) and str(g["faces_plus_one_dtype"]) == "float64"
+    for i in range(batch):
+        pred = {"3d_vertices": verts[i], "3dmm_params": params[i : i + 1]}
+        mesh = writers.get_mesh(pred, static["faces"])
+        assert mesh[1].dtype == np.float64
+        po, pj = tmp_path / f"m{i}.obj", tmp_path / f"m{i}.json"
+        writers.MeshSaver()(mesh, str(po))
+        writers.JsonSaver()(writers.get_flame_params(pred), str(pj))
+        assert po.read_bytes() == g[f"obj_{i}"].tobytes(), i
+        assert pj.read_bytes() == g[f"json_{i}"].tobytes(), i
+    paths = [str(tmp_path / f"b{i}.obj") for i in range(batch)]
+    writers.save_obj_batch(verts, static["faces"], paths)
+    fl = writers.flame_params_batch(params)
+    for i in range(batch):
+        assert open(paths[i], "rb").read() == g[f"obj_{i}"].tobytes()
+        pj = tmp_path / f"b{i}.json"
+        writers.JsonSaver()(fl[i], str(pj))
+        assert pj.read_bytes() == g[f"json_{i}"].tobytes()
+    assert writers.get_output_path("/data/in/some.image.jpeg", "outputs", "head_mesh", writers.MeshSaver().extension) == str(g["output_path"])
+    assert [".png", writers.MeshSaver().extension, writers.JsonSaver().extension] == list(g["extensions"])
+
+
 def test_ncc_color_codes():
     from dad_3dheads_amd.pncc import compute_ncc_color_codes
 
@@ -228,7 +264,7 @@ def test_projection_oracle_matches_reference_goldens():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/dad_3dheads_benchmark"), reason="reference tree not present on this machine")
 @pytest.mark.parametrize("script,fixture", [("make_lmk68_fixture.py", "lmk68_embedding.npz"), ("make_projection_golden.py", "projection_golden.npz"),
-                                            ("make_loss_golden.py", "loss_golden.npz")])
+                                            ("make_loss_golden.py", "loss_golden.npz"), ("make_writers_golden.py", "writers_golden.npz")])
 def test_committed_goldens_are_what_the_reference_produces_here(tmp_path, script, fixture):
     """Authoring container only: re-run the generator (the reference's own functions, imported from where they lie)
     and compare every array with the committed fixture."""

@@ -109,3 +109,36 @@ def test_predictor_geometry_helpers():
     flame_ref.readjust_3dmm(p, pads, scale)
     assert abs(p[0, 412].item() - (1 / scale - 1)) < 1e-6
     assert abs(p[0, 409].item() - ((1 - 25 * 2 / 256) / scale - 1)) < 1e-6
+
+
+def test_lbs_restatement_agrees_with_an_independent_float64_formulation(flame_model, flame_consts, decode_golden):
+    """VERDICT r1 missing #7: `flame_ref.lbs` (the restatement of third-party smplx.lbs that every decode golden passes
+    through) against oracle/lbs_independent.py -- written from the SMPL paper, float64, per vertex, scipy's exponential
+    map -- on the edge-case rows of the goldens (zero jaw, zero expression, large coefficients with a big jaw rotation) and
+    on full-pose inputs (neck, jaw, both eyeballs rotating) that the 413-parameter layout never produces."""
+    import torch
+
+    from oracle import flame_ref
+    from oracle.lbs_independent import lbs_per_vertex
+
+    fc = flame_consts
+    m = flame_model
+    posedirs = fc.posedirs.numpy().astype(np.float64)
+    args = (fc.v_template.numpy(), fc.shapedirs.numpy(), posedirs, fc.j_regressor.numpy(), fc.parents.numpy(), fc.lbs_weights.numpy())
+    rng = np.random.default_rng(12)
+    cases = []
+    for row in (0, 1, 5):  # zero jaw / zero expression / 4x coefficients + jaw (1.2, -0.7, 0.4)
+        p = decode_golden["edge_params"][row]
+        pose = np.zeros((5, 3), np.float32)
+        pose[2] = p[400:403]
+        cases.append((p[:400].copy(), pose))
+    for _ in range(2):  # every joint rotates (the generic 36-feature path), root included
+        cases.append(((rng.standard_normal(400) * 0.6).astype(np.float32), (rng.standard_normal((5, 3)) * 0.5).astype(np.float32)))
+    for betas, pose in cases:
+        v32, j32 = flame_ref.lbs(torch.from_numpy(betas)[None], torch.from_numpy(pose).reshape(1, 15), fc.v_template, fc.shapedirs,
+                                 fc.posedirs, fc.j_regressor, fc.parents, fc.lbs_weights)
+        v64, j64 = lbs_per_vertex(betas, pose, *args)
+        scale = max(1.0, float(np.abs(v64).max()))
+        assert np.abs(v32[0].numpy() - v64).max() < 1e-6 * scale, np.abs(v32[0].numpy() - v64).max()
+        assert np.abs(j32[0].numpy() - j64).max() < 1e-6 * scale
+    assert m.v_template.shape == (5023, 3)
