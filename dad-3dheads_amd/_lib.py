@@ -95,6 +95,7 @@ SIGNATURES = {
     "dad3d_mesh_render": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(LightC), _I, _P]),
     "dad3d_mesh_debug_trace": (_I, [_P, _P]),
     "dad3d_project_vertices": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "dad3d_preprocess_images": (_I, [_P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P]),
     "dad3d_sim3dr_get_tri_normal": (None, [_P, _P, _P, _I, _I]),
     "dad3d_sim3dr_get_ver_normal": (None, [_P, _P, _P, _I, _I]),
     "dad3d_sim3dr_get_normal": (None, [_P, _P, _P, _I, _I]),

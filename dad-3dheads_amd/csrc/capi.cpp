@@ -688,6 +688,18 @@ dad3d_status dad3d_project_vertices(const float* vertices, const float* model_vi
                                    static_cast<hipStream_t>(stream));
 }
 
+dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_size, const float* mean, const float* std,
+                                     float* out, int device, void* stream) {
+    DAD3D_REQUIRE(batch >= 0 && out_size > 0, "dad3d_preprocess_images: bad argument");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(descs && mean && std && out, "dad3d_preprocess_images: null argument");
+    DAD3D_REQUIRE(batch <= 65535 && out_size <= 65535, "dad3d_preprocess_images: batch / size beyond the launch grid");
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    return launch_preprocess(reinterpret_cast<const long long*>(descs), batch, out_size, mean, std, out,
+                             static_cast<hipStream_t>(stream));
+}
+
 dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer) {
     DAD3D_REQUIRE(m, "null handle");
     m->d_trace = device_buffer;

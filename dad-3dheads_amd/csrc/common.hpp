@@ -190,4 +190,9 @@ dad3d_status launch_project_vertices(const float* vertices, const float* model_v
                                      const float* frame, int batch, int nver, float* world_homo, float* xy, int32_t* xy_int,
                                      hipStream_t s);
 
+// predictor preprocessing (preprocess.hip): descs = [B][8] int64 on the device: {src pointer, h, w, new_h, new_w, pad_top,
+// pad_left, row stride in bytes}
+dad3d_status launch_preprocess(const long long* descs, int batch, int out_size, const float mean[3], const float std[3],
+                               float* out, hipStream_t s);
+
 }  // namespace dad3d

@@ -11,17 +11,18 @@ Same constructor (`config` dict with `model_path`, `img_size`, `stride`, `consta
 What is different underneath: the CNN runs on PyTorch-ROCm, its 413-vector never leaves HBM
 (the reference does `.detach().cpu()`, predictor.py:104), the re-adjustment is a HIP kernel and the TWO
 CPU decodes of predictor.py:136-137 are ONE fused HIP launch. `predict_batch` is the batched entry the
-reference lacks. Third-party preprocessing (albumentations / cv2, absent here) is restated in torch:
-LongestMaxSize(INTER_LINEAR) -> PadIfNeeded(centre, 0) -> Normalize(imagenet) (predictor.py:195-203).
+reference lacks. Third-party preprocessing (albumentations / cv2, absent here) is ONE HIP kernel for a batch of images
+of any sizes (`dad3d_preprocess_images`, csrc/preprocess.hip): LongestMaxSize (cv2 INTER_LINEAR, the 8-bit fixed-point
+path) -> PadIfNeeded(centre, 0) -> Normalize(imagenet) -> CHW (predictor.py:80-95,195-203).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from .head_mesh import HeadMesh
@@ -101,18 +102,28 @@ class FaceMeshPredictor:
         new_h, new_w = (py3round(d * scale) for d in (h, w))
         return calculate_paddings(new_h, new_w), scale, (new_h, new_w)
 
+    def _preprocess_launch(self, sources: Sequence[Tuple[int, int, int, int]]) -> torch.Tensor:
+        """sources: (device address, h, w, row stride in bytes) per image -> float32 [B,3,S,S] on the device, one launch."""
+        rows = []
+        for ptr, h, w, stride in sources:
+            pads, _, (nh, nw) = self._geometry((h, w))
+            rows.append([ptr, h, w, nh, nw, pads[0], pads[2], stride])
+        descs = torch.tensor(rows, dtype=torch.int64).to(self.device, non_blocking=False)
+        out = torch.empty((len(rows), 3, self._img_size, self._img_size), dtype=torch.float32, device=self.device)
+        mean, std = (C.c_float * 3)(*_MEAN), (C.c_float * 3)(*_STD)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.dad3d_preprocess_images(descs.data_ptr(), len(rows), self._img_size, mean, std, out.data_ptr(),
+                                                     self.cuda_id, stream))
+        return out
+
     def preprocess(self, x: np.ndarray, cache: Dict[str, Any]) -> torch.Tensor:
         cache["input_shape"] = x.shape[:2]
-        pads, _, (nh, nw) = self._geometry(x.shape[:2])
-        img = torch.from_numpy(np.ascontiguousarray(x)).to(self.device).permute(2, 0, 1)[None].float()
-        if (nh, nw) != tuple(x.shape[:2]):  # cv2.INTER_LINEAR: half-pixel centres, no antialiasing
-            img = F.interpolate(img, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
-            img = img.round().clamp_(0, 255)  # albumentations resizes the uint8 image
-        s = self._img_size
-        img = F.pad(img, (pads[2], s - nw - pads[2], pads[0], s - nh - pads[0]), value=0.0)
-        mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1) * 255.0
-        std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1) * 255.0
-        return (img - mean) / std
+        if x.ndim != 3 or x.shape[2] != 3 or x.dtype != np.uint8:
+            raise ValueError(f"expected a uint8 RGB image [H,W,3], got {x.dtype} {x.shape}")
+        img = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        out = self._preprocess_launch([(img.data_ptr(), x.shape[0], x.shape[1], x.shape[1] * 3)])
+        cache["_staged"] = img  # keeps the upload alive until the launch has consumed it (stream order)
+        return out
 
     def process(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         with torch.no_grad():
@@ -154,15 +165,9 @@ class FaceMeshPredictor:
         assert images.ndim == 4 and images.shape[-1] == 3 and images.dtype == torch.uint8 and images.is_cuda
         b, h, w = images.shape[:3]
         pads, scale, (nh, nw) = self._geometry((h, w))
-        x = images.permute(0, 3, 1, 2).float()
-        if (nh, nw) != (h, w):
-            x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False).round_().clamp_(0, 255)
-        s = self._img_size
-        if (nh, nw) != (s, s):
-            x = F.pad(x, (pads[2], s - nw - pads[2], pads[0], s - nh - pads[0]), value=0.0)
-        mean = torch.tensor(_MEAN, device=self.device).view(1, 3, 1, 1) * 255.0
-        std = torch.tensor(_STD, device=self.device).view(1, 3, 1, 1) * 255.0
-        out = self.process((x - mean) / std)
+        images = images.contiguous()
+        x = self._preprocess_launch([(images.data_ptr() + i * h * w * 3, h, w, w * 3) for i in range(b)])
+        out = self.process(x)
         params = out[OUTPUT_3DMM_PARAMS].detach().to(torch.float32).contiguous().clone()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         # one (pad_left, pad_top, scale) triple for the whole batch: pads_scale == NULL
@@ -183,8 +188,13 @@ class FaceMeshPredictor:
 
     def predict_batch(self, images: Sequence[np.ndarray], device_outputs: bool = False) -> List[Dict[str, Any]]:
         """Batched predictor: list of HxWx3 uint8 RGB arrays (any sizes) -> list of the reference's result dicts."""
-        caches: List[Dict[str, Any]] = [{} for _ in images]
-        batch = torch.cat([self.preprocess(im, c) for im, c in zip(images, caches)], dim=0)
+        caches: List[Dict[str, Any]] = [{"input_shape": im.shape[:2]} for im in images]
+        staged = []
+        for im in images:
+            if im.ndim != 3 or im.shape[2] != 3 or im.dtype != np.uint8:
+                raise ValueError(f"expected uint8 RGB images [H,W,3], got {im.dtype} {im.shape}")
+            staged.append(torch.from_numpy(np.ascontiguousarray(im)).to(self.device))
+        batch = self._preprocess_launch([(t.data_ptr(), t.shape[0], t.shape[1], t.shape[1] * 3) for t in staged])
         out = self.process(batch)
         params = out[OUTPUT_3DMM_PARAMS].detach().to(self.device, torch.float32).contiguous().clone()
         geo = [self._geometry(c["input_shape"]) for c in caches]

@@ -250,6 +250,17 @@ dad3d_status dad3d_project_vertices(const float* vertices, const float* model_vi
                                     const float* frame, int batch, int nver, float* world_homo, float* xy,
                                     int32_t* xy_int, int device, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * FaceMeshPredictor._transform + _array_to_batch (predictor.py:80-95,195-203) for a batch of uint8 RGB images of ANY sizes
+ * in one launch: LongestMaxSize (cv2.resize INTER_LINEAR, 8-bit fixed-point path) -> PadIfNeeded (centred, 0) -> Normalize
+ * ((x - 255 mean) * (1 / (255 std)), float32) -> CHW. All DEVICE pointers:
+ *   descs [B][8] int64: {address of the image's first byte (HWC, 3 channels), h, w, new_h, new_w, pad_top, pad_left, row
+ *                        stride in bytes}; the geometry (py3round, calculate_paddings: predictor.py:117-123) is the caller's
+ *   out   [B,3,out_size,out_size] float32
+ * mean/std: HOST arrays of 3 floats (the [0,1]-scale constants of A.Normalize). */
+dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_size, const float* mean, const float* std,
+                                     float* out, int device, void* stream);
+
 /* Single-image HOST entry points with the argument lists of Sim3DR/lib/rasterize.h:84-100 (`bool` spelled
  * `int` for C). libdad3d_hip.so additionally exports the C++-linkage symbols `_get_tri_normal`,
  * `_get_ver_normal`, `_get_normal`, `_rasterize_triangles`, `_rasterize` with the reference's exact

@@ -11,5 +11,5 @@ tmp="$(mktemp -d)"; cp "$src" "$S/_alt_variant.hip"; trap 'rm -f "$S/_alt_varian
 (cd "$S" && make -s)   # the other objects are the product's
 $H $C -c "$S/_alt_variant.hip" -o "$tmp/fd.o"
 $H $C -DDAD3D_DIAG_SPIN_ENV -x hip -c "$S/capi.cpp" -o "$tmp/capi.o"   # honours DAD3D_SPIN_LIMIT
-$H --offload-arch=gfx950 -shared -fPIC -o "$out" "$tmp/fd.o" "$tmp/capi.o" "$S/flame_backward.o" "$S/sim3dr_kernels.o" "$S/projection.o" "$S/sim3dr_compat.o"
+$H --offload-arch=gfx950 -shared -fPIC -o "$out" "$tmp/fd.o" "$tmp/capi.o" "$S/flame_backward.o" "$S/sim3dr_kernels.o" "$S/projection.o" "$S/preprocess.o" "$S/sim3dr_compat.o"
 echo "built $out"
