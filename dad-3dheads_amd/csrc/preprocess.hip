@@ -8,8 +8,8 @@
 //
 // One lane per output pixel (three channels), output rows contiguous per channel plane: a streaming kernel, 3 B read per
 // tap (4 taps) and 12 B written per pixel; the batch of 64 x 256^2 is 50 MB of output, HBM-bound. Third-party cv2 and
-// albumentations are absent from the image: the arithmetic is restated from their published sources, the numpy
-// oracle oracle/preprocess_ref.py restates it once more, and the two are held bit for bit (tests/test_gpu_preprocess.py).
+// albumentations are absent from the image: the arithmetic is restated from their published sources; the test
+// suite restates it once more in numpy and holds this kernel to it bit for bit (tests/test_preprocess.py).
 #include "common.hpp"
 
 namespace dad3d {
