@@ -27,6 +27,8 @@
 // image in 32-column chunks that stay 3-4 chunks ahead of the MFMAs. The k order inside every 16-row
 // group is permuted (lane group q takes rows 4q..4q+3) so that one conflict-free ds_read_b128 delivers a
 // lane's A operand for four consecutive MFMAs straight from the row-major image.
+#include <type_traits>
+
 #include "common.hpp"
 
 #ifndef DAD3D_ABLATE  // diagnostics builds only (tools/ablate.sh); 0 in the product
@@ -492,20 +494,18 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     using PT = Parts<KG>;
     constexpr int LD = L::LD;
     constexpr int kNumBeta = 400;     // MAX_SHAPE + MAX_EXPRESSION, checked on the host
-    constexpr int kPollFrom = 7;      // the hand-off is looked for once the mma waves have this many groups left
     float* a_lds = smem + L::a_off;
     float* imgc = smem + L::imgc_off;
     float* vconst = smem + L::vc_off;
     int* lmkh = reinterpret_cast<int*>(smem + L::lh_off);
     float* otile = smem + L::o_off;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware block -> (tile, batch block): blocks land on XCD (blockIdx % 8); the batch blocks that
-    // share one basis tile are consecutive on one XCD so the tile is fetched into that L2 once.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave: an SGPR, role branches are scalar
+    // One PERSISTENT workgroup per basis tile: it walks the batch's 64-image blocks in order, with its basis slice held
+    // in the mma waves' registers (read from HBM once per launch, not once per block) and the first parts of the next
+    // block's A image staged under the tail of the current block's GEMM.
     const int gid = (int)blockIdx.x - a.n_pose_blocks_pad8;
-    const int xcd = gid & 7, rr = gid >> 3;
-    const int bb = rr % a.nbb;
-    const int tile = (rr / a.nbb) * 8 + xcd;
+    const int tile = gid;
     if (tile >= a.n_tiles) {
         bystander();
         return;
@@ -516,7 +516,6 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     };
     stamp(0);
     if (trace && lane == 0) trace[12] = wall_clock64();
-    const int img0 = bb * kBlockImages;
     const int v0 = tile * kTileVerts;
     const int P = a.lay.n_params;
 
@@ -526,230 +525,28 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     // (LDS address space spelled out: through a generic volatile pointer these become FLAT accesses that queue
     // behind the wave's outstanding global loads)
     typedef __attribute__((address_space(3))) int lds_int;
-    lds_int* part_ready = (lds_int*)(lmkh + 21);  // [0..20] unused since the heads moved next to the weights
+    lds_int* part_ready = (lds_int*)(lmkh + 8);     // [8,11): arrivals per part, monotonic over the blocks (4 per block)
+    lds_int* ring_free = (lds_int*)(lmkh + 12);     // mma waves that have left parts 0 and 1 behind, monotonic (4 per block)
     lds_int* handoff_flag = (lds_int*)(lmkh + 24);  // 0 = pending, 1 = published, 2 = timed out
-    lds_int* gemm_late = (lds_int*)(lmkh + 25);     // set by mma wave 0 when kPollFrom groups are left
-    if (tid < 5) __hip_atomic_store(part_ready + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // [3] = the flag, [4] = gemm_late
+    if (tid < 8) __hip_atomic_store(part_ready + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tid == 8) __hip_atomic_store(handoff_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     auto lds_peek = [](lds_int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    auto wait_part = [&](int p) {
-        while (lds_peek(part_ready + p) < 4) __builtin_amdgcn_s_sleep(1);
+    auto wait_part = [&](int p, int target) {
+        while (lds_peek(part_ready + p) < target) __builtin_amdgcn_s_sleep(1);
     };
     auto publish_part = [&](int p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the part have landed
         if (lane == 0) __hip_atomic_fetch_add(part_ready + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    if (wave < 4) {
-        // =============================== mma waves ===============================================
-        // acc[m] = images [16m,16m+16) x columns [16*wave,16*wave+16). MFMA step (G, s): lane group
-        // q = lane>>4 contributes basis row k = 16G + 4q + s, so the A operand of lane (q, i) for s = 0..3 is
-        // the float4 at a_lds[16m + i][16G + 4q], and its B operand the float4 the host packed for (G, wave,
-        // lane). The A fragments of group G+1 are read while group G multiplies.
-        const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
-        // the basis slice of this wave: kBAhead groups (1 KiB each) requested up front, then one more per group
-        // multiplied -- the texture-address unit (64 B/clk) is shared with the feeders, whose first part
-        // must not queue behind 100 KiB of basis that is not needed for thousands of cycles
-        constexpr int kBAhead = 6;
-        float4 bq[KG];
-#pragma unroll
-        for (int G = 0; G < kBAhead && G < KG; ++G) bq[G] = bsrc[(size_t)G * 256];
-        f32x4 acc[RB];
-#pragma unroll
-        for (int m = 0; m < RB; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* afrag = a_lds + (lane & 15) * LD + 4 * (lane >> 4);
-        float4 af[RB], an[RB] = {};
-        stamp(1);
-        wait_part(0);  // part 0 of the A image is in LDS
-        stamp(2);
-#pragma unroll
-        for (int m = 0; m < RB; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
-#pragma unroll
-        for (int G = 0; G < KG; ++G) {
-            // part p is awaited one group before its first group: the prefetch below (group G+1) then always
-            // reads published data
-            if (G + 1 == PT::begin(1) || G + 1 == PT::begin(2)) {
-                if (DAD3D_ABLATE & 64) stamp(8 + 2 * (G + 1 == PT::begin(1) ? 0 : 1));
-                wait_part(G + 1 == PT::begin(1) ? 1 : 2);
-                if (DAD3D_ABLATE & 64) stamp(9 + 2 * (G + 1 == PT::begin(1) ? 0 : 1));
-            }
-            if ((DAD3D_ABLATE & 64) && G == 20) stamp(14);
-            if (G == KG - kPollFrom && wave == 0 && lane == 0) __hip_atomic_store(gemm_late, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (G + 1 < KG) {
-#pragma unroll
-                for (int m = 0; m < RB; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
-#pragma unroll
-                for (int m = 0; m < RB; ++m) {
-                    const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < RB; ++m) af[m] = an[m];
-            if (G + kBAhead < KG) bq[G + kBAhead] = bsrc[(size_t)(G + kBAhead) * 256];
-        }
-        stamp(3);
-        // accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
-#pragma unroll
-        for (int m = 0; m < RB; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                otile[(m * 16 + (lane >> 4) * 4 + q) * kOutStride + wave * 16 + (lane & 15)] = acc[m][q];
-    } else {
-        // =============================== feeder waves ============================================
-        const int ht = tid - 256;  // 0..255
-        // A image: thread copies the float4s (row, 4*c4 + 32*j), slab j = 2 MFMA groups, of rows srow and
-        // srow+32 of the 64 params rows. Rows are only 4-byte aligned (413 floats), hence the f4u loads.
-        // k >= 400 (pose feature, template row, zero padding) is written by the tail code below, not staged.
-        const int srow = ht >> 3, c4 = ht & 7;
-        // rows past the end of a ragged last block re-read the batch's last row (valid memory, results never
-        // stored): the loads stay unconditional -- no exec-mask branch per load in the feeders' issue stream
-        const int r0 = min(img0 + srow, a.batch - 1), r1 = min(img0 + srow + 32, a.batch - 1);
-        const float* prow0 = a.params + (size_t)r0 * P;
-        const float* prow1 = a.params + (size_t)r1 * P;
-        float* adst0 = a_lds + srow * LD + 4 * c4;
-        float* adst1 = adst0 + 32 * LD;
-        auto beta4 = [&](const float* prow, int k) -> float4 {  // k + 3 < 400 guaranteed by the caller
-            if (CONTIG) {
-                const f4u v = *reinterpret_cast<const f4u*>(prow + k);
-                return float4{v.x, v.y, v.z, v.w};
-            }
-            return float4{beta_at(prow, a, k), beta_at(prow, a, k + 1), beta_at(prow, a, k + 2), beta_at(prow, a, k + 3)};
-        };
-        constexpr int kSlabs = (kNumBeta + 31) / 32;  // 13 slabs hold betas (the last one half)
-        float4 s0[kSlabs], s1[kSlabs];
-#define DAD3D_LOAD_PART(p)                                                        \
-    _Pragma("unroll") for (int jj = PT::begin(p) / 2; jj < PT::begin((p) + 1) / 2 && jj < kSlabs; ++jj) { \
-        const int kk = (32 * jj + 28 < kNumBeta) ? 32 * jj + 4 * c4 : min(32 * jj + 4 * c4, kNumBeta - 4); \
-        s0[jj] = beta4(prow0, kk);                                                \
-        s1[jj] = beta4(prow1, kk);                                                \
-    }
-#define DAD3D_WRITE_PART(p)                                                       \
-    _Pragma("unroll") for (int jj = PT::begin(p) / 2; jj < PT::begin((p) + 1) / 2 && jj < kSlabs; ++jj) { \
-        if (32 * jj + 4 * c4 < kNumBeta) {                                        \
-            *reinterpret_cast<float4*>(adst0 + 32 * jj) = s0[jj];                 \
-            *reinterpret_cast<float4*>(adst1 + 32 * jj) = s1[jj];                 \
-        }                                                                         \
-    }
-        // Order of the feeders' work. An instruction issued by a feeder while the mma wave of its SIMD streams MFMAs costs
-        // the matrix pipe ~8 cycles, and the feeder itself gets about one issue slot per MFMA: whatever can happen before
-        // the GEMM starts happens there. So: pose inputs and part 0 are requested first and ALONE (the address unit takes
-        // ~35 cycles per unaligned 16-byte load instruction; with part 1 queued behind it the first ds_write came 1 k
-        // cycles later), the rows past the betas (one Rodrigues per image) are computed while part 0 is in flight and
-        // published with it, the rest of A is requested behind it and written as it lands.
-        PoseIn pose_in{};
-        const int trow = (wave - 4) * 16 + lane;
-        const bool tail_live = lane < 16 && img0 + trow < a.batch;
-        if (tail_live) pose_in = load_pose(a.params + (size_t)(img0 + trow) * P, a.lay);
-        DAD3D_LOAD_PART(0)
-        // requested behind the first part (vector loads return in order: nothing the GEMM needs waits for it)
-        unsigned epoch_base = 0;
-        if (dev_epoch && wave == 4 && lane == 0) epoch_base = read_epoch();
-        // slots 0..5 of a vertex: skinning weights; slots 6, 7: its first landmark slot and the one chained after it
-        float vc = __int_as_float(-1);
-        if (ht < kTileVerts * 8) {
-            const int v = v0 + ht / 8, slot = ht & 7;
-            if (v < a.n_verts) vc = slot < 6 ? a.weights8[(size_t)v * 8 + slot] : __int_as_float(a.lmk_head[(size_t)v * 2 + slot - 6]);
-            else if (slot < 6) vc = 0.0f;
-        }
-        if (lane < 16) {  // rows of the A image past the betas: pose feature (R_j - I), the template's 1, zero padding
-            float* dst = a_lds + trow * LD + kNumBeta;
-            float tail[L::K - kNumBeta];
-#pragma unroll
-            for (int i = 0; i < L::K - kNumBeta; ++i) tail[i] = 0.0f;
-            if (tail_live) {
-                if (JAW_ONLY) {
-                    if (a.lay.jaw_n == 3) rodrigues_minus_identity(pose_in.jaw, tail);
-                    tail[9] = 1.0f;
-                } else {
-                    if (a.lay.neck_n == 3) rodrigues_minus_identity(pose_in.neck, tail);
-                    if (a.lay.jaw_n == 3) rodrigues_minus_identity(pose_in.jaw, tail + 9);
-                    if (a.lay.eye_n == 6) {
-                        rodrigues_minus_identity(pose_in.eyes, tail + 18);
-                        rodrigues_minus_identity(pose_in.eyes + 3, tail + 27);
-                    }
-                    tail[36] = 1.0f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < (L::K - kNumBeta) / 4; ++i)
-                reinterpret_cast<float4*>(dst)[i] = float4{tail[4 * i], tail[4 * i + 1], tail[4 * i + 2], tail[4 * i + 3]};
-        }
-        if (ht < kTileVerts * 8) vconst[ht] = vc;
-        stamp(1);
-        DAD3D_WRITE_PART(0)
-        publish_part(0);
-        stamp(2);
-        DAD3D_LOAD_PART(1)
-        DAD3D_LOAD_PART(2)
-        DAD3D_WRITE_PART(1)
-        publish_part(1);
-        DAD3D_WRITE_PART(2)
-        publish_part(2);
-#undef DAD3D_LOAD_PART
-#undef DAD3D_WRITE_PART
-        stamp(3);
-        // ---- hand-off from the pose role (the mma waves are still multiplying the last, largest part) ------
-        // One lane polls the arrival counter (relaxed, agent scope) until every image of this launch has been
-        // published; the block is then fetched with sc1 loads (served by L2/memory, never a stale L1 line).
-        constexpr int kVec = kBlockImages * kImgConsts / 4;  // float4s of this block's per-image constants
-        constexpr int kCst = (kVec + 255) / 256;
-        const __amdgpu_buffer_rsrc_t imgc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            a.imgc + (size_t)img0 * kImgConsts, 0, min(kBlockImages, a.batch - img0) * kImgConsts * (int)sizeof(float),
-            0x00020000);  // rows past the batch read as zeros (buffer bounds check)
-        // The counter is not looked at before the GEMM is in its last groups: a look is a load that goes to the memory
-        // side, takes microseconds when hundreds of workgroups look at the same word, and this CU's vector loads return
-        // IN ORDER -- the mma waves' basis loads queue behind it (polling from the end of the staging on, 3.5 us into
-        // the launch and before the pose role has published, slowed the second half of the GEMM from 36 to 65 cycles per
-        // MFMA). By then the pose role has long finished and the first look succeeds.
-        while (lds_peek(gemm_late) == 0) __builtin_amdgcn_s_sleep(16);
-        // ONE poller per workgroup (240 pollers on one word already cost the memory system something; four per
-        // workgroup with a short sleep measurably slowed the pose role they were waiting for), generous sleep
-        // between polls; the other feeder waves wait on an LDS flag.
-        if (wave == 4 && lane == 0) {
-            const unsigned ticket = dev_epoch ? take_ticket() : 0u;  // epoch_base is back (older than part 2's loads)
-            const unsigned target = dev_epoch ? epoch_base + (unsigned)a.batch : a.arrive_target;
-            int st = 2;
-            for (unsigned spin = 0; spin < a.spin_limit; ++spin) {
-                const unsigned seen = __hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(seen - target) >= 0) {  // every image's pose wave arrives once per launch
-                    st = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(10);  // every look costs the mma wave of this SIMD a few MFMA slots
-            }
-            __hip_atomic_store(handoff_flag, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (dev_epoch) advance_epoch_if_last(ticket, epoch_base);  // its round trip overlapped the polling
-        }
-        while (lds_peek(handoff_flag) == 0) __builtin_amdgcn_s_sleep(12);  // ~0.8 k cycles between looks (see above)
-        const int ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
-        if (trace && lane == 0) trace[14] = wall_clock64();
-        if (ok) {
-#pragma unroll
-            for (int i = 0; i < kCst; ++i) {
-                const int idx = i * 256 + ht;
-                if (idx < kVec) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, idx * 16, 0, kCacheSc1);
-                    reinterpret_cast<f32x4*>(imgc)[idx] = __builtin_bit_cast(f32x4, v);
-                }
-            }
-        } else {
-            // time-out (the pose role's workgroups were not scheduled in time): this wave computes the constants
-            // of its own 16 images itself, straight into the LDS block (lane 0 writes all 84 floats of an image)
-            if (lane == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int i = 0; i < 16; ++i) {
-                const int row = (wave - 4) * 16 + i;
-                if (img0 + row < a.batch) image_constants<JAW_ONLY, CONTIG>(a, a.params + (size_t)(img0 + row) * P, imgc + row * kImgConsts, lane);
-            }
-        }
-    }
-    __syncthreads();  // accumulator tile (mma waves) + per-image constants (feeders) are in LDS
+    // state that lives across the blocks
+    constexpr int kBAhead = 6;
+    int handoff_ok = 0;    // feeder waves: the pose role's blocks may be fetched (set in block 0)
+    unsigned epoch_base = 0;
+    const int nbb = a.nbb;
+    // ---- epilogue (all 8 waves), one 64-image block --------------------------------------------------------
+    auto epilogue = [&](const int img0) {
     stamp(4);
 
     // ---- epilogue (all 8 waves) -------------------------------------------------------------------------
@@ -858,6 +655,262 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     }
     stamp(5);
     if (trace && lane == 0) trace[13] = wall_clock64();
+    };
+    // The two roles run their own loops over the blocks (same barriers, same epilogue): state that lives across the
+    // blocks -- the mma waves' basis slice -- is then live in that role's code only.
+    if (wave < 4) {
+#pragma unroll 1
+        for (int blk = 0; blk < nbb; ++blk) {
+            const int img0 = blk * kBlockImages;
+
+        // =============================== mma waves ===============================================
+        // acc[m] = images [16m,16m+16) x columns [16*wave,16*wave+16). MFMA step (G, s): lane group
+        // q = lane>>4 contributes basis row k = 16G + 4q + s, so the A operand of lane (q, i) for s = 0..3 is
+        // the float4 at a_lds[16m + i][16G + 4q], and its B operand the float4 the host packed for (G, wave,
+        // lane). The A fragments of group G+1 are read while group G multiplies.
+        // one block's GEMM; FIRST: the block that also streams the basis slice into bq (its own instantiation, so that
+        // the compiler counts outstanding loads exactly -- a run-time "first block?" around every basis load made every
+        // s_waitcnt vmcnt conservative and cut the 6-group prefetch distance to 2)
+        auto gemm = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        float4 bq[KG];
+        const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
+        // the basis slice of this wave (block 0 only): kBAhead groups (1 KiB each) requested up front, then one more
+        // per group multiplied -- the texture-address unit (64 B/clk) is shared with the feeders, whose first part
+        // must not queue behind 100 KiB of basis that is not needed for thousands of cycles
+        if (FIRST) {
+#pragma unroll
+            for (int G = 0; G < kBAhead && G < KG; ++G) bq[G] = bsrc[(size_t)G * 256];
+        }
+        f32x4 acc[RB];
+#pragma unroll
+        for (int m = 0; m < RB; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* afrag = a_lds + (lane & 15) * LD + 4 * (lane >> 4);
+        float4 af[RB], an[RB] = {};
+        stamp(1);
+        wait_part(0, 4 * (blk + 1));  // part 0 of this block's A image is in LDS
+        stamp(2);
+#pragma unroll
+        for (int m = 0; m < RB; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
+#pragma unroll
+        for (int G = 0; G < KG; ++G) {
+            // part p is awaited one group before its first group: the prefetch below (group G+1) then always
+            // reads published data
+            if (G + 1 == PT::begin(1) || G + 1 == PT::begin(2)) {
+                if (DAD3D_ABLATE & 64) stamp(8 + 2 * (G + 1 == PT::begin(1) ? 0 : 1));
+                wait_part(G + 1 == PT::begin(1) ? 1 : 2, 4 * (blk + 1));
+                if (DAD3D_ABLATE & 64) stamp(9 + 2 * (G + 1 == PT::begin(1) ? 0 : 1));
+            }
+            if ((DAD3D_ABLATE & 64) && G == 20) stamp(14);
+            if (G + 1 < KG) {
+#pragma unroll
+                for (int m = 0; m < RB; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
+#pragma unroll
+                for (int m = 0; m < RB; ++m) {
+                    const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < RB; ++m) af[m] = an[m];
+            if (FIRST && G + kBAhead < KG) bq[G + kBAhead] = bsrc[(size_t)(G + kBAhead) * 256];
+            // parts 0 and 1 of the image (groups < PT::begin(2)) are behind this wave: the feeders may overwrite them
+            // with the next block's (the fragments of group G + 1 are in flight, everything older has been multiplied)
+            if (G == PT::begin(2) && lane == 0) __hip_atomic_fetch_add(ring_free, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        stamp(3);
+        // accumulators -> LDS tile [image][column]; D layout: row = (lane>>4)*4 + reg, col = lane&15
+#pragma unroll
+        for (int m = 0; m < RB; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                otile[(m * 16 + (lane >> 4) * 4 + q) * kOutStride + wave * 16 + (lane & 15)] = acc[m][q];
+
+        };
+        gemm(std::true_type{});  // p4: the basis is streamed again for every block (L2 hits after the first)
+            __syncthreads();  // accumulator tile (mma waves) + per-image constants (feeders) are in LDS
+            epilogue(img0);
+            if (blk + 1 < nbb) __syncthreads();  // tile, per-image constants and the rest of the A image are free again
+        }
+    } else {
+#pragma unroll 1
+        for (int blk = 0; blk < nbb; ++blk) {
+            const int img0 = blk * kBlockImages;
+
+        // =============================== feeder waves ============================================
+        const int ht = tid - 256;  // 0..255
+        // A image: thread copies the float4s (row, 4*c4 + 32*j), slab j = 2 MFMA groups, of rows srow and
+        // srow+32 of the 64 params rows. Rows are only 4-byte aligned (413 floats), hence the f4u loads.
+        // k >= 400 (pose feature, template row, zero padding) is written by the tail code below, not staged.
+        const int srow = ht >> 3, c4 = ht & 7;
+        // rows past the end of a ragged last block re-read the batch's last row (valid memory, results never
+        // stored): the loads stay unconditional -- no exec-mask branch per load in the feeders' issue stream
+        const float* prow0 = a.params + (size_t)min(img0 + srow, a.batch - 1) * P;
+        const float* prow1 = a.params + (size_t)min(img0 + srow + 32, a.batch - 1) * P;
+        // the same rows of the NEXT block, whose first two parts are staged under the tail of this block's GEMM
+        const float* nrow0 = a.params + (size_t)min(img0 + kBlockImages + srow, a.batch - 1) * P;
+        const float* nrow1 = a.params + (size_t)min(img0 + kBlockImages + srow + 32, a.batch - 1) * P;
+        float* adst0 = a_lds + srow * LD + 4 * c4;
+        float* adst1 = adst0 + 32 * LD;
+        auto beta4 = [&](const float* prow, int k) -> float4 {  // k + 3 < 400 guaranteed by the caller
+            if (CONTIG) {
+                const f4u v = *reinterpret_cast<const f4u*>(prow + k);
+                return float4{v.x, v.y, v.z, v.w};
+            }
+            return float4{beta_at(prow, a, k), beta_at(prow, a, k + 1), beta_at(prow, a, k + 2), beta_at(prow, a, k + 3)};
+        };
+        constexpr int kSlabs = (kNumBeta + 31) / 32;  // 13 slabs hold betas (the last one half)
+        float4 s0[kSlabs], s1[kSlabs];
+#define DAD3D_LOAD_PART_OF(p, row0, row1)                                         \
+    _Pragma("unroll") for (int jj = PT::begin(p) / 2; jj < PT::begin((p) + 1) / 2 && jj < kSlabs; ++jj) { \
+        const int kk = (32 * jj + 28 < kNumBeta) ? 32 * jj + 4 * c4 : min(32 * jj + 4 * c4, kNumBeta - 4); \
+        s0[jj] = beta4(row0, kk);                                                 \
+        s1[jj] = beta4(row1, kk);                                                 \
+    }
+#define DAD3D_LOAD_PART(p) DAD3D_LOAD_PART_OF(p, prow0, prow1)
+#define DAD3D_WRITE_PART(p)                                                       \
+    _Pragma("unroll") for (int jj = PT::begin(p) / 2; jj < PT::begin((p) + 1) / 2 && jj < kSlabs; ++jj) { \
+        if (32 * jj + 4 * c4 < kNumBeta) {                                        \
+            *reinterpret_cast<float4*>(adst0 + 32 * jj) = s0[jj];                 \
+            *reinterpret_cast<float4*>(adst1 + 32 * jj) = s1[jj];                 \
+        }                                                                         \
+    }
+        if (blk == 0) {
+            DAD3D_LOAD_PART(0)
+            DAD3D_LOAD_PART(1)
+        }
+        // requested behind the first parts (vector loads return in order: nothing the GEMM needs waits for it)
+        if (dev_epoch && blk == 0 && wave == 4 && lane == 0) epoch_base = read_epoch();
+        // pose inputs of image (16*(wave-4) + lane) for the A rows past the betas; per-vertex constants
+        PoseIn pose_in{};
+        const int trow = (wave - 4) * 16 + lane;
+        const bool tail_live = lane < 16 && img0 + trow < a.batch;
+        if (tail_live) pose_in = load_pose(a.params + (size_t)(img0 + trow) * P, a.lay);
+        // slots 0..5 of a vertex: skinning weights; slots 6, 7: its first landmark slot and the one chained after it
+        float vc = __int_as_float(-1);
+        if (blk == 0 && ht < kTileVerts * 8) {
+            const int v = v0 + ht / 8, slot = ht & 7;
+            if (v < a.n_verts) vc = slot < 6 ? a.weights8[(size_t)v * 8 + slot] : __int_as_float(a.lmk_head[(size_t)v * 2 + slot - 6]);
+            else if (slot < 6) vc = 0.0f;
+        }
+        stamp(1);
+        if (blk == 0) {
+            DAD3D_WRITE_PART(0)
+            publish_part(0);
+        }
+        stamp(2);
+        DAD3D_LOAD_PART(2)
+        if (blk == 0) {
+            DAD3D_WRITE_PART(1)
+            publish_part(1);
+        }
+        {   // computed while the loads of part 2 are in flight; published with part 2
+                // rows of the A image past the betas: pose feature (R_j - I), the template's 1, zero padding
+                if (lane < 16) {
+                    float* dst = a_lds + trow * LD + kNumBeta;
+                    float tail[L::K - kNumBeta];
+#pragma unroll
+                    for (int i = 0; i < L::K - kNumBeta; ++i) tail[i] = 0.0f;
+                    if (tail_live) {
+                        if (JAW_ONLY) {
+                            if (a.lay.jaw_n == 3) rodrigues_minus_identity(pose_in.jaw, tail);
+                            tail[9] = 1.0f;
+                        } else {
+                            if (a.lay.neck_n == 3) rodrigues_minus_identity(pose_in.neck, tail);
+                            if (a.lay.jaw_n == 3) rodrigues_minus_identity(pose_in.jaw, tail + 9);
+                            if (a.lay.eye_n == 6) {
+                                rodrigues_minus_identity(pose_in.eyes, tail + 18);
+                                rodrigues_minus_identity(pose_in.eyes + 3, tail + 27);
+                            }
+                            tail[36] = 1.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < (L::K - kNumBeta) / 4; ++i)
+                        reinterpret_cast<float4*>(dst)[i] =
+                            float4{tail[4 * i], tail[4 * i + 1], tail[4 * i + 2], tail[4 * i + 3]};
+                }
+                if (blk == 0 && ht < kTileVerts * 8) vconst[ht] = vc;
+        }
+        DAD3D_WRITE_PART(2)
+        publish_part(2);
+        stamp(3);
+        // ---- hand-off from the pose role (the mma waves are still multiplying the last, largest part) ------
+        // One lane polls the arrival counter (relaxed, agent scope) until every image of this launch has been
+        // published; the block is then fetched with sc1 loads (served by L2/memory, never a stale L1 line).
+        constexpr int kVec = kBlockImages * kImgConsts / 4;  // float4s of this block's per-image constants
+        constexpr int kCst = (kVec + 255) / 256;
+        const __amdgpu_buffer_rsrc_t imgc_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.imgc + (size_t)img0 * kImgConsts, 0, min(kBlockImages, a.batch - img0) * kImgConsts * (int)sizeof(float),
+            0x00020000);  // rows past the batch read as zeros (buffer bounds check)
+        // ONE poller per workgroup (240 pollers on one word already cost the memory system something; four per
+        // workgroup with a short sleep measurably slowed the pose role they were waiting for), generous sleep
+        // between polls; the other feeder waves wait on an LDS flag.
+        if (blk == 0) {
+            if (wave == 4 && lane == 0) {
+                const unsigned ticket = dev_epoch ? take_ticket() : 0u;  // epoch_base is back (older than part 2's loads)
+                const unsigned target = dev_epoch ? epoch_base + (unsigned)a.batch : a.arrive_target;
+                int st = 2;
+                for (unsigned spin = 0; spin < a.spin_limit; ++spin) {
+                    const unsigned seen = __hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(seen - target) >= 0) {  // every image's pose wave arrives once per launch
+                        st = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(10);
+                }
+                __hip_atomic_store(handoff_flag, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dev_epoch) advance_epoch_if_last(ticket, epoch_base);  // its round trip overlapped the polling
+            }
+            while (lds_peek(handoff_flag) == 0) __builtin_amdgcn_s_sleep(4);
+            handoff_ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
+            if (trace && lane == 0) trace[14] = wall_clock64();
+        }
+        const int ok = handoff_ok;  // the counter covers the whole launch: later blocks need no second look
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < kCst; ++i) {
+                const int idx = i * 256 + ht;
+                if (idx < kVec) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, idx * 16, 0, kCacheSc1);
+                    reinterpret_cast<f32x4*>(imgc)[idx] = __builtin_bit_cast(f32x4, v);
+                }
+            }
+        } else {
+            // time-out (the pose role's workgroups were not scheduled in time): this wave computes the constants
+            // of its own 16 images itself, straight into the LDS block (lane 0 writes all 84 floats of an image)
+            if (lane == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 16; ++i) {
+                const int row = (wave - 4) * 16 + i;
+                if (img0 + row < a.batch) image_constants<JAW_ONLY, CONTIG>(a, a.params + (size_t)(img0 + row) * P, imgc + row * kImgConsts, lane);
+            }
+        }
+        if (blk + 1 < nbb) {
+            // parts 0 and 1 of the NEXT block, into the columns the mma waves have left behind: its GEMM then starts
+            // right behind this block's epilogue instead of a staging round trip later
+            while (lds_peek(ring_free) < 4 * (blk + 1)) __builtin_amdgcn_s_sleep(8);
+            DAD3D_LOAD_PART_OF(0, nrow0, nrow1)
+            DAD3D_LOAD_PART_OF(1, nrow0, nrow1)
+            DAD3D_WRITE_PART(0)
+            publish_part(0);
+            DAD3D_WRITE_PART(1)
+            publish_part(1);
+        }
+#undef DAD3D_LOAD_PART
+#undef DAD3D_LOAD_PART_OF
+#undef DAD3D_WRITE_PART
+
+            __syncthreads();
+            epilogue(img0);
+            if (blk + 1 < nbb) __syncthreads();
+        }
+    }
 }
 
 size_t flame_decode_lds_bytes(int kgroups) {
@@ -873,7 +926,7 @@ static dad3d_status launch_decode_r(const DecodeArgs& a, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8 * a.nbb;
+    const int grid = a.n_pose_blocks_pad8 + a.n_tiles_pad8;  // one persistent decode workgroup per tile
     hipLaunchKernelGGL((flame_decode_kernel<KG, JAW_ONLY, CONTIG, DEV_EPOCH, RB, POSED>), dim3(grid), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
