@@ -10,6 +10,11 @@ plumbing, not accuracy):
     fusion    1x1 conv over [stage3, sigmoid(heatmap), P5]    flame_regression.py:28-43, then ResNet stage 4 (:91-93)
     heads     avg-pool -> 512 -> {403 tanh*3, 10, 136 relu}   flame_regression.py:46-59, 94-99
 
+Module NAMES differ from the reference's `FlameRegression` (`fusion` / `heatmap` / `bifpn.lateral` here,
+`fusion_layer.conv1x1` / `head.heatmap` / `bifpn.p3..p5` there) and BatchNorm is folded for inference, so a reference
+Lightning checkpoint cannot be loaded into this declaration as is; the trained model is used through its TorchScript file
+(`FaceMeshPredictor(config)` -> `torch.jit.load`, predictor.py:72), exactly like the reference's predictor does.
+
 `forward` returns the reference's output dict (`landmarks_heatmap`, `3dmm_params` [B,413], `2d_landmarks` [B,68,2]).
 Inference runs channels-last in bf16 (MIOpen / hipBLASLt underneath); the 413 parameters are cast to fp32 on the way
 out because the decode computes in fp32. PyTorch is plumbing here: this file contains no custom kernels.
@@ -35,12 +40,16 @@ def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, relu: bool = True) ->
 
 
 class Bottleneck(nn.Module):
-    """ResNet-v1.5 bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 x4, projection shortcut when the shape changes."""
+    """ResNet bottleneck: 1x1 -> 3x3 -> 1x1 x4, projection shortcut when the shape changes. The reference's backbone is
+    pytorchcv's `resnet50` (encoders.py:5,52; config/model/resnet_regression.yaml:3), which is built with
+    `conv1_stride=True`: the stride sits on the FIRST 1x1 convolution (the original v1 placement), not on the 3x3 of
+    torchvision's v1.5 -- that is what is declared here (`stride_on_first=False` gives the v1.5 variant, `resnet50b`)."""
 
-    def __init__(self, cin: int, width: int, stride: int):
+    def __init__(self, cin: int, width: int, stride: int, stride_on_first: bool = True):
         super().__init__()
         cout = 4 * width
-        self.body = nn.Sequential(_conv_bn(cin, width, 1), _conv_bn(width, width, 3, stride), _conv_bn(width, cout, 1, relu=False))
+        s1, s3 = (stride, 1) if stride_on_first else (1, stride)
+        self.body = nn.Sequential(_conv_bn(cin, width, 1, s1), _conv_bn(width, width, 3, s3), _conv_bn(width, cout, 1, relu=False))
         self.shortcut = None if (stride == 1 and cin == cout) else _conv_bn(cin, cout, 1, stride, relu=False)
 
     def forward(self, x: Tensor) -> Tensor:
