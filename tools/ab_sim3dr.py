@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Diagnostics: A/B timing of the Sim3DR kernels for the library in $DAD3D_LIB_PATH: normals, normals + Phong, geometry +
+tiles (rasterize), render, per 64 decoded heads at 256 x 256; bit-exactness of image 0 against the C port."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dad_3dheads_amd import landmarks, synthetic
+from dad_3dheads_amd.head_mesh import HeadMesh
+from dad_3dheads_amd.Sim3DR import Mesh
+from oracle.sim3dr_ref import Sim3DROracle
+
+tag = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.environ.get("DAD3D_LIB_PATH", "product"))
+st = synthetic.load_static()
+hm = HeadMesh(flame_model=synthetic.synthetic_flame_model(0, st), landmarks=landmarks.canonical("445", st), static=st, device=0)
+B = 64
+p = torch.from_numpy(synthetic.synthetic_params(B, seed=2)).cuda()
+verts = hm.flame.decode(p, proj=True, to_2d=False, flip_z=True)["proj"].clone()
+faces = st["faces"]
+mesh = Mesh(faces, 5023, device=0)
+
+def t(fn, iters=300, warm=30):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+    return best
+
+normals = mesh.get_normal(verts)
+light = mesh.phong_light(verts, normals)
+img = torch.zeros((B, 256, 256, 3), dtype=torch.uint8, device="cuda")
+lbuf = torch.empty_like(verts)
+res = {"normals": t(lambda: mesh.get_normal(verts, out=normals)), "normals+phong": t(lambda: mesh.phong_light(verts, None)),
+       "rasterize": t(lambda: mesh.rasterize(verts, light, img)), "render": t(lambda: mesh.render(verts, img, light_out=lbuf))}
+orc = Sim3DROracle("port")
+v0 = np.ascontiguousarray(verts[0].cpu().numpy())
+ok_n = np.array_equal(orc.get_normal(v0, faces), mesh.get_normal(verts)[0].cpu().numpy())
+img.zero_(); mesh.rasterize(verts, light, img); torch.cuda.synchronize()
+ok_r = np.array_equal(orc.rasterize(v0, faces, light[0].cpu().numpy(), height=256, width=256, channel=3), img[0].cpu().numpy())
+print(f"AB3D {tag:24s} " + "  ".join(f"{k} {v:6.2f} us" for k, v in res.items()) + f"  normals_exact {ok_n} raster_exact {ok_r}", flush=True)
