@@ -171,16 +171,26 @@ def main() -> None:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():
+    # TEST HOOK (tests/test_gpu_sharding.py, a box with ONE GPU): DAD3D_BENCH_SHARE_GPU=1 lets every rank use device
+    # (local_rank mod visible) and joins them over gloo with host-staged gathers -- the N > 1 code path (shard seeds, the
+    # per-rank timed regions, MAX over ranks, the gather's placement and its check) then runs on real kernels. RCCL refuses
+    # two ranks on one device, so this is NOT the multi-GPU measurement: the line says so in `config.parallelism`.
+    share_gpu = os.environ.get("DAD3D_BENCH_SHARE_GPU") == "1" and under_launcher
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if under_launcher:  # under torch.distributed.run, even N = 1: the RCCL path is the one that is timed
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+            _stage_gathers_through_the_host(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from dad_3dheads_amd import _lib, landmarks, synthetic
     from dad_3dheads_amd.head_mesh import HeadMesh
@@ -188,7 +198,7 @@ def main() -> None:
     static = synthetic.load_static()
     model = synthetic.synthetic_flame_model(0, static)
     lmk_idx = landmarks.canonical("445", static)
-    hm = HeadMesh(flame_model=model, landmarks=lmk_idx, static=static, device=local_rank)
+    hm = HeadMesh(flame_model=model, landmarks=lmk_idx, static=static, device=dev_index)
     lib = _lib.load()
     run = run_render if args.workload == "render" else run_decode
     out = run(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx)
@@ -197,6 +207,26 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _stage_gathers_through_the_host(dist):
+    """Test hook only: gloo has no device all_gather_into_tensor / all_reduce / barrier for HIP tensors everywhere, so the
+    three collectives bench.py uses are wrapped to go through host copies. Never active on the measured (nccl) path."""
+    real_gather, real_reduce = dist.all_gather_into_tensor, dist.all_reduce
+
+    def gather(out, inp, group=None):
+        torch.cuda.synchronize()
+        o, i = out.cpu(), inp.cpu().contiguous()
+        real_gather(o, i, group=group)
+        out.copy_(o)
+
+    def reduce(t, op=dist.ReduceOp.SUM, group=None):
+        c = t.cpu()
+        real_reduce(c, op=op, group=group)
+        t.copy_(c)
+
+    dist.all_gather_into_tensor, dist.all_reduce = gather, reduce
+    dist._dad3d_shared_gpu = True
 
 
 def fence(dist, dev):
@@ -346,7 +376,9 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
             "batch_per_gpu": BATCH,
             "global_batch": world * BATCH,
             "parallelism": f"image-sharded x{world}, one final RCCL all-gather of landmarks"
-                           + (" (process group: nccl)" if dist is not None else " (no process group: plain N=1 run)"),
+                           + ((" (TEST HOOK: ranks share one GPU, gloo with host-staged gathers -- not a multi-GPU measurement)"
+                               if getattr(dist, "_dad3d_shared_gpu", False) else " (process group: nccl)")
+                              if dist is not None else " (no process group: plain N=1 run)"),
             "streams": n_streams,
             "prewarm_ms": prewarm_ms,
             "value_from": "hipEvents on the launch stream around the K timed launches (MAX over ranks)" if from_events

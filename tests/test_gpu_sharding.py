@@ -153,3 +153,29 @@ def test_bench_plain_and_torchrun_lines_agree_and_two_gpus_are_refused():
     if torch.cuda.device_count() < 2:
         two = _run_bench(base + ["--gpus", "2", "--steps", "5", "--warmup", "1"], timeout=120)
         assert two.returncode != 0 and "2 GPUs requested, 1 visible" in two.stderr, two.stderr[-500:]
+
+
+def test_bench_two_ranks_code_path_on_one_gpu():
+    """N > 1 has never run on multi-GPU hardware (no such box is available to the builder). What CAN run here: the whole
+    N = 2 code path of bench.py -- two ranks under torch.distributed.run, per-rank seeds and buffers, barrier + synchronize
+    brackets, MAX over ranks, the final gather of 2 x 64 x 445 landmarks and its check -- with both ranks sharing the one GPU
+    and the collective on gloo (RCCL refuses two ranks per device). The line must say that it is not a multi-GPU measurement."""
+    env_extra = {"DAD3D_BENCH_SHARE_GPU": "1"}
+    for workload, steps in (("decode", "300"), ("render", "60")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--gpus", "2", "--steps", steps,
+               "--warmup", "20", "--workload", workload]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
+        env.update(env_extra)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-1500:]
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+        if workload == "decode":
+            assert d["config"]["outputs_verified"] is True and d["config"]["handoff_timeouts"] == 0
+            assert "not a multi-GPU measurement" in d["config"]["parallelism"]
+        else:
+            assert d["config"]["gather_verified"] is True and d["config"]["images_with_coverage"] == 1.0
+        assert d["value"] > 0
