@@ -556,6 +556,9 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     if (tid == 0) sc.qhdr[2] = 0;
 }
 
+typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+
 struct RasterArgs {
     MeshDev m;
     RasterScratch sc;
@@ -842,7 +845,10 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             for (int k = 0; k < NP; ++k) {
                 const float4* rp = rec_b + (size_t)f[k] * kRecF4;
                 r0[k] = rp[0], r1[k] = rp[1], z1[k] = rp[2].x, z2[k] = rp[2].y;
-                if (MODE == 0) i0[k] = a.m.tri[3 * f[k]], i1[k] = a.m.tri[3 * f[k] + 1], i2[k] = a.m.tri[3 * f[k] + 2];
+                if (MODE == 0) {  // one 12-byte gather (4-byte aligned) instead of three
+                    const int3u t3 = *reinterpret_cast<const int3u*>(a.m.tri + 3 * (size_t)f[k]);
+                    i0[k] = t3.x, i1[k] = t3.y, i2[k] = t3.z;
+                }
             }
             float u[NP], v[NP], w0[NP], z[NP];
 #pragma unroll
@@ -857,10 +863,20 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             float col[NP][3 * CC];
             if (packed) {
 #pragma unroll
-                for (int k = 0; k < NP; ++k)
+                for (int k = 0; k < NP; ++k) {
+                    if (C == 3) {  // a corner's colour is 12 contiguous bytes: one gather per corner
+                        const float3u q0 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i0[k]);
+                        const float3u q1 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i1[k]);
+                        const float3u q2 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i2[k]);
+                        col[k][0] = q0.x, col[k][1] = q0.y, col[k][2] = q0.z;
+                        col[k][C] = q1.x, col[k][C + 1] = q1.y, col[k][C + 2] = q1.z;
+                        col[k][2 * C] = q2.x, col[k][2 * C + 1] = q2.y, col[k][2 * C + 2] = q2.z;
+                    } else {
 #pragma unroll
-                    for (int ch = 0; ch < C; ++ch)
-                        col[k][ch] = cb_[C * i0[k] + ch], col[k][C + ch] = cb_[C * i1[k] + ch], col[k][2 * C + ch] = cb_[C * i2[k] + ch];
+                        for (int ch = 0; ch < C; ++ch)
+                            col[k][ch] = cb_[C * i0[k] + ch], col[k][C + ch] = cb_[C * i1[k] + ch], col[k][2 * C + ch] = cb_[C * i2[k] + ch];
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
