@@ -11,11 +11,14 @@ plumbing, not accuracy):
     heads     avg-pool -> 512 -> {403 tanh*3, 10, 136 relu}   flame_regression.py:46-59, 94-99
 
 Module NAMES differ from the reference's `FlameRegression` (`fusion` / `heatmap` / `bifpn.lateral` here,
-`fusion_layer.conv1x1` / `head.heatmap` / `bifpn.p3..p5` there) and BatchNorm is folded for inference, so a reference
-Lightning checkpoint cannot be loaded into this declaration as is; the trained model is used through its TorchScript file
-(`FaceMeshPredictor(config)` -> `torch.jit.load`, predictor.py:72), exactly like the reference's predictor does.
+`fusion_layer.conv1x1` / `head.heatmap` / `bifpn.p3..p5` there): `convert_reference_state_dict` renames a reference
+(Lightning) state dict, `DAD3DNet.load_reference_state_dict` loads it strictly. tests/test_network_reference.py runs the
+reference's own FlameRegression / BiFPN / heads live, moves its weights across and compares the outputs. The trained
+model is otherwise used through its TorchScript file (`FaceMeshPredictor(config)` -> `torch.jit.load`, predictor.py:72),
+exactly like the reference's predictor does.
 
-`forward` returns the reference's output dict (`landmarks_heatmap`, `3dmm_params` [B,413], `2d_landmarks` [B,68,2]).
+`forward` returns the reference's output dict (`OUTPUT_LANDMARKS_HEATMAP`, `OUTPUT_3DMM_PARAMS` [B,413],
+`OUTPUT_2D_LANDMARKS` [B,68,2]: flame_regression.py:100-104).
 Inference runs channels-last in bf16 (MIOpen / hipBLASLt underneath); the 413 parameters are cast to fp32 on the way
 out because the decode computes in fp32. PyTorch is plumbing here: this file contains no custom kernels.
 """
@@ -27,9 +30,11 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-OUTPUT_3DMM_PARAMS = "3dmm_params"
-OUTPUT_2D_LANDMARKS = "2d_landmarks"
-OUTPUT_LANDMARKS_HEATMAP = "landmarks_heatmap"
+# keys of the network's output dict: the VALUES model_training/data/config.py:16-23 gives these names (each constant's
+# value is its own name) -- what the reference's TorchScript checkpoint returns and predictor.py:103-109 looks up
+OUTPUT_3DMM_PARAMS = "OUTPUT_3DMM_PARAMS"
+OUTPUT_2D_LANDMARKS = "OUTPUT_2D_LANDMARKS"
+OUTPUT_LANDMARKS_HEATMAP = "OUTPUT_LANDMARKS_HEATMAP"
 
 
 def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, relu: bool = True) -> nn.Sequential:
@@ -179,6 +184,11 @@ class DAD3DNet(nn.Module):
             torch.random.set_rng_state(gen_state)
         self.limit_value = limit_value
 
+    def load_reference_state_dict(self, state: Dict[str, Tensor], strict: bool = True):
+        """Load the weights of a reference `FlameRegression` (its `state_dict()` or the `state_dict` entry of a
+        Lightning checkpoint) into this declaration; to be called BEFORE `InferenceNet` folds the BatchNorms."""
+        return self.load_state_dict(convert_reference_state_dict(state), strict=strict)
+
     def forward(self, x: Tensor) -> Dict[str, Tensor]:
         stages = self.encoder.stages
         feats = []
@@ -194,6 +204,57 @@ class DAD3DNet(nn.Module):
         lmk = F.relu(self.landmarks(top)).reshape(x.shape[0], -1, 2)
         return {OUTPUT_LANDMARKS_HEATMAP: heatmap, OUTPUT_3DMM_PARAMS: torch.cat([shape, self.pose(top)], dim=1),
                 OUTPUT_2D_LANDMARKS: lmk}
+
+
+_TD_SLOT = {"p6_td": 0, "p5_td": 1, "p4_td": 2, "p3_td": 3}      # BiFPNBlock.td, top-down order (bifpn.py:84-87)
+_OUT_SLOT = {"p4_out": 0, "p5_out": 1, "p6_out": 2, "p7_out": 3}  # BiFPNBlock.out, bottom-up order (bifpn.py:89-92)
+
+
+def convert_reference_state_dict(state: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Key names of the reference's `FlameRegression.state_dict()` -> the names of `DAD3DNet`. Accepts the optional
+    `model.` prefix a Lightning checkpoint puts in front (model_training/model/utils.py:20-27 strips it the same way).
+
+        encoder.model.init_block.conv.{conv,bn}                 -> encoder.stages.0.0.{0,1}      (pytorchcv's names:
+        encoder.model.stage{s}.unit{u}.body.conv{c}.{conv,bn}   -> encoder.stages.{s}.{u-1}.body.{c-1}.{0,1}   encoders.py:22,
+        encoder.model.stage{s}.unit{u}.identity_conv.{conv,bn}  -> encoder.stages.{s}.{u-1}.shortcut.{0,1}     45-47)
+        bifpn.p{3,4,5}  -> bifpn.lateral.{0,1,2}     bifpn.p7.{conv,bn} -> bifpn.p7.{0,1}        (bifpn.py:137-146)
+        bifpn.bifpn.{i}.{p6_td..p3_td, p4_out..p7_out, w1, w2} -> bifpn.blocks.{i}.{td.k, out.k, w_td, w_out}
+        head.heatmap -> heatmap    fusion_layer.conv1x1 -> fusion    {shape,pose,landmarks}.logit_image -> .mlp
+    """
+    import re
+
+    out: Dict[str, Tensor] = {}
+    for key, value in state.items():
+        k = key[len("model."):] if key.startswith("model.") else key
+        if k.startswith("encoder.model."):
+            k = k[len("encoder.model."):]
+            k = re.sub(r"^init_block\.conv\.conv\.", "encoder.stages.0.0.0.", k)
+            k = re.sub(r"^init_block\.conv\.bn\.", "encoder.stages.0.0.1.", k)
+            m = re.match(r"^stage(\d+)\.unit(\d+)\.(body\.conv(\d)|identity_conv)\.(conv|bn)\.(.+)$", k)
+            if m:
+                where = f"body.{int(m.group(4)) - 1}" if m.group(4) else "shortcut"
+                k = f"encoder.stages.{m.group(1)}.{int(m.group(2)) - 1}.{where}.{0 if m.group(5) == 'conv' else 1}.{m.group(6)}"
+            elif not k.startswith("encoder.stages."):
+                raise KeyError(f"unexpected encoder entry in the reference state dict: {key}")
+        else:
+            k = re.sub(r"^bifpn\.p([345])\.", lambda m: f"bifpn.lateral.{int(m.group(1)) - 3}.", k)
+            k = re.sub(r"^bifpn\.p7\.conv\.", "bifpn.p7.0.", k)
+            k = re.sub(r"^bifpn\.p7\.bn\.", "bifpn.p7.1.", k)
+            m = re.match(r"^bifpn\.bifpn\.(\d+)\.(\w+?)(\..+)?$", k)
+            if m:
+                name, rest = m.group(2), m.group(3) or ""
+                if name in _TD_SLOT:
+                    name = f"td.{_TD_SLOT[name]}"
+                elif name in _OUT_SLOT:
+                    name = f"out.{_OUT_SLOT[name]}"
+                else:
+                    name = {"w1": "w_td", "w2": "w_out"}[name]
+                k = f"bifpn.blocks.{m.group(1)}.{name}{rest}"
+            k = re.sub(r"^head\.heatmap\.", "heatmap.", k)
+            k = re.sub(r"^fusion_layer\.conv1x1\.", "fusion.", k)
+            k = re.sub(r"^(shape|pose|landmarks)\.logit_image\.", r"\1.mlp.", k)
+        out[k] = value
+    return out
 
 
 @torch.no_grad()

@@ -27,9 +27,10 @@ import torch
 from . import _lib
 from .head_mesh import HeadMesh
 
-OUTPUT_3DMM_PARAMS = "3dmm_params"          # model_training/data/config.py (keys of the CNN's output dict)
-OUTPUT_2D_LANDMARKS = "2d_landmarks"
-OUTPUT_LANDMARKS_HEATMAP = "landmarks_heatmap"
+# keys of the CNN's output dict (model_training/data/config.py:16-23: every constant's value is its own name)
+OUTPUT_3DMM_PARAMS = "OUTPUT_3DMM_PARAMS"
+OUTPUT_2D_LANDMARKS = "OUTPUT_2D_LANDMARKS"
+OUTPUT_LANDMARKS_HEATMAP = "OUTPUT_LANDMARKS_HEATMAP"
 _MEAN = (0.485, 0.456, 0.406)
 _STD = (0.229, 0.224, 0.225)
 

@@ -117,3 +117,111 @@ def load_reference_losses(model):
     v3d = importlib.import_module("model_training.losses.vertices_3d_loss")
     rep = importlib.import_module("model_training.losses.reprojection_loss")
     return v3d.Vertices3DLoss, rep.ReprojectionLoss
+
+
+def _pytorchcv_resnet50_features():
+    """Stand-in for `pytorchcv.model_provider.get_model("resnet50").features` (encoders.py:5,22; the package is not
+    installed here, pinned by the reference's requirements as a third-party dependency): a module tree with pytorchcv's
+    published resnet50 layout and NAMES -- `init_block.conv.{conv,bn}`, `stage{1..4}.unit{k}.body.conv{1,2,3}.{conv,bn}`,
+    `unit1.identity_conv.{conv,bn}`, stride on conv1 of a unit's bottleneck (`conv1_stride=True`) -- written from the
+    architecture, random-initialised. It exists so that the reference's own FlameRegression / BiFPN / heads can be
+    executed and so that a state dict with the checkpoint's key names exists; it pins nothing about pytorchcv itself."""
+    from torch import nn
+
+    class ConvBlock(nn.Module):
+        def __init__(self, cin, cout, k, stride=1, activ=True):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+            self.bn = nn.BatchNorm2d(cout)
+            self.activ = nn.ReLU(inplace=True) if activ else None
+
+        def forward(self, x):
+            x = self.bn(self.conv(x))
+            return x if self.activ is None else self.activ(x)
+
+    class ResBottleneck(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            mid = cout // 4
+            self.conv1 = ConvBlock(cin, mid, 1, stride)
+            self.conv2 = ConvBlock(mid, mid, 3)
+            self.conv3 = ConvBlock(mid, cout, 1, activ=False)
+
+        def forward(self, x):
+            return self.conv3(self.conv2(self.conv1(x)))
+
+    class ResUnit(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.resize_identity = cin != cout or stride != 1
+            self.body = ResBottleneck(cin, cout, stride)
+            if self.resize_identity:
+                self.identity_conv = ConvBlock(cin, cout, 1, stride, activ=False)
+            self.activ = nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            identity = self.identity_conv(x) if self.resize_identity else x
+            return self.activ(self.body(x) + identity)
+
+    class ResInitBlock(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = ConvBlock(3, 64, 7, 2)
+            self.pool = nn.MaxPool2d(3, 2, 1)
+
+        def forward(self, x):
+            return self.pool(self.conv(x))
+
+    features = nn.Sequential()
+    features.add_module("init_block", ResInitBlock())
+    cin = 64
+    for i, (cout, units) in enumerate(((256, 3), (512, 4), (1024, 6), (2048, 3))):
+        stage = nn.Sequential()
+        for j in range(units):
+            stage.add_module(f"unit{j + 1}", ResUnit(cin, cout, 2 if (j == 0 and i != 0) else 1))
+            cin = cout
+        features.add_module(f"stage{i + 1}", stage)
+    return features
+
+
+def load_reference_regressor(seed: int = 0, num_classes: int = 68):
+    """The reference's own `FlameRegression` (model_training/model/flame_regression.py:62-105, with its bifpn.py,
+    layers.py and encoders.py, unmodified) on the resnet50 configuration of config/model/resnet_regression.yaml,
+    random-initialised from `seed`. Stand-ins: `pytorchcv.model_provider.get_model` (see above),
+    `pytorch_toolbelt.modules` (imported by layers.py:8, used only by heads this model does not build), `hydra`."""
+    if not reference_available():
+        raise FileNotFoundError(f"reference tree not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    if "pytorch_toolbelt.modules" not in sys.modules:
+        mods = types.ModuleType("pytorch_toolbelt.modules")
+        sys.modules["pytorch_toolbelt.modules"] = mods
+        sys.modules["pytorch_toolbelt"].modules = mods
+    if "pytorchcv" not in sys.modules:
+        cv = types.ModuleType("pytorchcv")
+        provider = types.ModuleType("pytorchcv.model_provider")
+        cv.model_provider = provider
+        sys.modules["pytorchcv"], sys.modules["pytorchcv.model_provider"] = cv, provider
+
+        def get_model(name, pretrained=False, **kwargs):
+            if name != "resnet50":
+                raise ValueError(f"stand-in only declares resnet50, not {name}")
+            return types.SimpleNamespace(features=_pytorchcv_resnet50_features())
+
+        provider.get_model = get_model
+    if "model_training.data" not in sys.modules:  # its __init__ pulls in the datasets (albumentations, cv2): bypassed,
+        pkg = types.ModuleType("model_training.data")  # only data/config.py (string constants) is needed
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, "model_training", "data")]
+        sys.modules["model_training.data"] = pkg
+    from model_training.model.flame_regression import FlameRegression  # noqa: E402  (reference code)
+
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        cfg = {"backbone": "resnet50", "pretrained": False, "num_filters": 256, "num_channels": 3,
+               "num_classes": num_classes, "img_size": 256, "conv_block": "regular", "limit_value": 3}
+        return FlameRegression(cfg, {}, num_classes=num_classes)
+    finally:
+        torch.random.set_rng_state(state)

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 class StandInRegressor(torch.nn.Module):
-    """Output contract of DAD-3DNet: {"3dmm_params": [B,413], "2d_landmarks": [B,68,2] in [0,1]}."""
+    """Output contract of DAD-3DNet: {"OUTPUT_3DMM_PARAMS": [B,413], "OUTPUT_2D_LANDMARKS": [B,68,2] in [0,1]} -- the key
+    strings of model_training/data/config.py:16-23, which the reference's TorchScript checkpoint returns."""
 
     def __init__(self):
         super().__init__()
@@ -26,7 +27,7 @@ class StandInRegressor(torch.nn.Module):
         feat = x.mean(dim=(2, 3))  # [B,3]
         p = self.base[None] + 0.05 * torch.tanh(feat @ self.w)
         lm = torch.sigmoid(feat[:, :2])[:, None, :].expand(-1, 68, -1) * torch.linspace(0.2, 0.9, 68, device=x.device)[None, :, None]
-        return {"3dmm_params": p, "2d_landmarks": lm}
+        return {"OUTPUT_3DMM_PARAMS": p, "OUTPUT_2D_LANDMARKS": lm}
 
 
 @pytest.fixture(scope="module")
@@ -39,8 +40,8 @@ def reference_postprocess(pred, image, flame_consts):
     cache = {}
     x = pred.preprocess(image, cache)
     out = pred.process(x)
-    params = out["3dmm_params"].detach().cpu().clone()
-    lm = out["2d_landmarks"].detach().cpu().numpy() * 256.0
+    params = out["OUTPUT_3DMM_PARAMS"].detach().cpu().clone()
+    lm = out["OUTPUT_2D_LANDMARKS"].detach().cpu().numpy() * 256.0
     pads, scale = flame_ref.get_paddings(image.shape[:2])
     pts = lm.clip(min=0, max=256) - np.array([[pads[2], pads[0]]])
     pts = (pts / scale).astype(int).reshape(-1, 2)
@@ -107,10 +108,10 @@ def net_predictor(flame_model):
 def test_network_output_contract(net_predictor):
     x = torch.randn(3, 3, 256, 256, device="cuda")
     out = net_predictor.process(x)
-    assert out["3dmm_params"].shape == (3, 413) and out["3dmm_params"].dtype == torch.float32
-    assert out["2d_landmarks"].shape == (3, 68, 2) and (out["2d_landmarks"] >= 0).all()
-    assert out["landmarks_heatmap"].shape == (3, 68, 64, 64)
-    assert out["3dmm_params"][:, :403].abs().max() <= 3.0  # tanh * limit_value (flame_regression.py:94)
+    assert out["OUTPUT_3DMM_PARAMS"].shape == (3, 413) and out["OUTPUT_3DMM_PARAMS"].dtype == torch.float32
+    assert out["OUTPUT_2D_LANDMARKS"].shape == (3, 68, 2) and (out["OUTPUT_2D_LANDMARKS"] >= 0).all()
+    assert out["OUTPUT_LANDMARKS_HEATMAP"].shape == (3, 68, 64, 64)
+    assert out["OUTPUT_3DMM_PARAMS"][:, :403].abs().max() <= 3.0  # tanh * limit_value (flame_regression.py:94)
 
 
 @pytest.mark.parametrize("hw", [(256, 256), (320, 240)])
@@ -135,8 +136,8 @@ def test_device_resident_batch_matches_reference_postprocess(net_predictor, flam
     # the batched device-side normalisation equals the per-image preprocess of the single-image path
     x = torch.cat([net_predictor.preprocess(im, {}) for im in images.cpu().numpy()])
     assert torch.allclose(seen["x"], x, atol=1e-5)
-    params = seen["out"]["3dmm_params"].detach().cpu().clone()
-    lm68 = seen["out"]["2d_landmarks"].detach().cpu().numpy() * 256.0
+    params = seen["out"]["OUTPUT_3DMM_PARAMS"].detach().cpu().clone()
+    lm68 = seen["out"]["OUTPUT_2D_LANDMARKS"].detach().cpu().numpy() * 256.0
     pads, scale = flame_ref.get_paddings(hw)
     params = flame_ref.readjust_3dmm(params, pads, scale)
     v3d = flame_ref.vertices_3d(flame_consts, params)

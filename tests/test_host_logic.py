@@ -107,11 +107,11 @@ def test_dad3dnet_declaration_matches_the_reference_output_contract():
         feats.append(tuple(f.shape[1:]))
     assert feats == [(64, 64, 64), (256, 64, 64), (512, 32, 32), (1024, 16, 16), (2048, 8, 8)]
     out = InferenceNet(net, torch.float32)(torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)))
-    assert out["3dmm_params"].shape == (1, 413) and out["2d_landmarks"].shape == (1, 68, 2)
-    assert out["landmarks_heatmap"].shape == (1, 68, 64, 64)
-    assert out["3dmm_params"][:, :403].abs().max() <= 3.0 and (out["2d_landmarks"] >= 0).all()
+    assert out["OUTPUT_3DMM_PARAMS"].shape == (1, 413) and out["OUTPUT_2D_LANDMARKS"].shape == (1, 68, 2)
+    assert out["OUTPUT_LANDMARKS_HEATMAP"].shape == (1, 68, 64, 64)
+    assert out["OUTPUT_3DMM_PARAMS"][:, :403].abs().max() <= 3.0 and (out["OUTPUT_2D_LANDMARKS"] >= 0).all()
     again = InferenceNet(DAD3DNet(seed=0), torch.float32)(torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(0)))
-    assert torch.equal(out["3dmm_params"], again["3dmm_params"])  # seeded initialisation
+    assert torch.equal(out["OUTPUT_3DMM_PARAMS"], again["OUTPUT_3DMM_PARAMS"])  # seeded initialisation
     # BatchNorm folding is an exact rewrite up to rounding (non-trivial statistics to make it a real check)
     raw = DAD3DNet(seed=0).eval()
     g = torch.Generator().manual_seed(3)

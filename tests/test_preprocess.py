@@ -59,7 +59,7 @@ def test_fixed_point_resize_is_float_bilinear_to_within_rounding(hw):
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
 class StandInRegressor(torch.nn.Module):
-    """Output contract of DAD-3DNet: {"3dmm_params": [B,413], "2d_landmarks": [B,68,2] in [0,1]} (flame_regression.py:96-104)."""
+    """Output contract of DAD-3DNet: {"OUTPUT_3DMM_PARAMS": [B,413], "OUTPUT_2D_LANDMARKS": [B,68,2] in [0,1]} (flame_regression.py:96-104)."""
 
     def __init__(self):
         super().__init__()
@@ -73,7 +73,7 @@ class StandInRegressor(torch.nn.Module):
         feat = x.mean(dim=(2, 3))
         p = self.base[None] + 0.05 * torch.tanh(feat @ self.w)
         lm = torch.sigmoid(feat[:, :2])[:, None, :].expand(-1, 68, -1) * torch.linspace(0.2, 0.9, 68, device=x.device)[None, :, None]
-        return {"3dmm_params": p, "2d_landmarks": lm}
+        return {"OUTPUT_3DMM_PARAMS": p, "OUTPUT_2D_LANDMARKS": lm}
 
 
 @pytest.fixture(scope="module")
@@ -128,7 +128,7 @@ def test_config0_demo_image_to_flame_params_json(predictor, flame_consts, tmp_pa
     # the reference's path on the CPU from the same network output
     x = torch.from_numpy(pr.transform(img))[None].cuda()
     net_out = predictor.process(x)
-    params = net_out["3dmm_params"].detach().cpu().clone()
+    params = net_out["OUTPUT_3DMM_PARAMS"].detach().cpu().clone()
     pads, scale = flame_ref.get_paddings(img.shape[:2])
     assert pads == [0, 0, 25, 25] and abs(scale - 256 / 954) < 1e-15
     params = flame_ref.readjust_3dmm(params, pads, scale)
@@ -139,6 +139,6 @@ def test_config0_demo_image_to_flame_params_json(predictor, flame_consts, tmp_pa
     for k in got:
         assert np.allclose(got[k], want[k], rtol=0, atol=2e-6), k
     assert got["translation"][2] == 0.0 and got["eyeballs"] == [] and len(got["shape"]) == 300
-    lm = net_out["2d_landmarks"].detach().cpu().numpy() * 256.0
+    lm = net_out["OUTPUT_2D_LANDMARKS"].detach().cpu().numpy() * 256.0
     pts = ((lm.clip(min=0, max=256) - np.array([[pads[2], pads[0]]])) / scale).astype(int).reshape(-1, 2)
     assert np.array_equal(res["points"], pts)

@@ -38,7 +38,7 @@ def main():
         x = torch.randn(batch, 3, 256, 256, device="cuda")
         t_all = timed(lambda: pred.predict_tensor(images), 20, 5)
         t_cnn = timed(lambda: pred.process(x), 20, 5)
-        params = pred.process(x)["3dmm_params"].contiguous()
+        params = pred.process(x)["OUTPUT_3DMM_PARAMS"].contiguous()
         t_dec = timed(lambda: pred.head_mesh.decode(params, landmarks=False, landmarks_px=True), 200, 20)
         out[name] = {"images_per_s_end_to_end": batch / t_all, "ms_per_batch_end_to_end": t_all * 1e3,
                      "ms_cnn_only": t_cnn * 1e3, "ms_decode_only": t_dec * 1e3,
