@@ -22,11 +22,12 @@ class StandInRegressor(torch.nn.Module):
         g = torch.Generator().manual_seed(0)
         self.register_buffer("w", torch.randn(3, 413, generator=g) * 0.5)
         self.register_buffer("base", torch.from_numpy(synthetic.synthetic_params(1, seed=8))[0])
+        self.register_buffer("ramp", torch.linspace(0.2, 0.9, 68)[None, :, None])  # a buffer: follows .to() when traced
 
     def forward(self, x):
         feat = x.mean(dim=(2, 3))  # [B,3]
         p = self.base[None] + 0.05 * torch.tanh(feat @ self.w)
-        lm = torch.sigmoid(feat[:, :2])[:, None, :].expand(-1, 68, -1) * torch.linspace(0.2, 0.9, 68, device=x.device)[None, :, None]
+        lm = torch.sigmoid(feat[:, :2])[:, None, :].expand(-1, 68, -1) * self.ramp
         return {"OUTPUT_3DMM_PARAMS": p, "OUTPUT_2D_LANDMARKS": lm}
 
 
@@ -95,6 +96,25 @@ def test_missing_checkpoint_is_a_loud_error(flame_model, tmp_path, monkeypatch):
     monkeypatch.setenv("HOME", str(tmp_path))
     with pytest.raises(FileNotFoundError, match="no network"):
         FaceMeshPredictor(load_default_config(), cuda_id=0, flame_model=flame_model)
+
+
+def test_torchscript_checkpoint_path(flame_model, flame_consts, tmp_path, monkeypatch):
+    """The reference's construction path (predictor.py:72): `torch.jit.load($HOME/<model_path>)` of a scripted module that
+    returns the reference's output keys (model_training/data/config.py:16-23) -- no `model=` argument."""
+    monkeypatch.setenv("HOME", str(tmp_path))
+    config = load_default_config()
+    path = tmp_path / config["model_path"]
+    path.parent.mkdir(parents=True, exist_ok=True)
+    example = torch.zeros(1, 3, 256, 256)
+    torch.jit.trace(StandInRegressor(), example, strict=False).save(str(path))
+    pred = FaceMeshPredictor(config, cuda_id=0, flame_model=flame_model)
+    assert isinstance(pred.model, torch.jit.ScriptModule)
+    image = np.random.default_rng(3).integers(0, 255, (300, 260, 3), dtype=np.uint8)
+    res = pred(image)
+    pts, proj, v3d, params = reference_postprocess(pred, image, flame_consts)
+    assert np.array_equal(res["points"], pts)
+    assert (res["3dmm_params"] - params).abs().max() < 1e-5
+    assert (res["3d_vertices"] - v3d).abs().max() < 5e-6
 
 
 # ---- DAD-3DNet front half declared for PyTorch-ROCm (SURVEY 8f-1) ------------------------------------------------

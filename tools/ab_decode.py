@@ -3,7 +3,7 @@
 
     DAD3D_LIB_PATH=tools/_variants/lib_x.so python tools/ab_decode.py [tag]
 
-Prints one line: hipEvent us/launch at B = 64 / 256 / 1024 (445-landmark path, all outputs), golden check of the B = 64
+Prints one line: hipEvent us/launch at B = 64 / 128 / 256 / 1024 (445-landmark path, all outputs), golden check of the B = 64
 outputs (tests/golden/decode_golden.npz, the reference's own HeadMesh), hand-off time-outs."""
 import ctypes as C
 import os
@@ -22,7 +22,7 @@ hm = HeadMesh(flame_model=synthetic.synthetic_flame_model(0, st), landmarks=land
 lib = _lib.load()
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "decode_golden.npz"))
 res = {}
-for b, iters in ((64, 3000), (256, 1000), (1024, 300)):
+for b, iters in ((64, 3000), (128, 1500), (256, 1000), (1024, 300)):
     p = torch.from_numpy(g["b64_params"] if b == 64 else synthetic.synthetic_params(b, seed=b)).cuda()
     v3 = torch.empty((b, 5023, 3), device="cuda"); pr = torch.empty((b, 5023, 2), device="cuda")
     lp = torch.empty((b, 445, 2), dtype=torch.int32, device="cuda")
@@ -39,6 +39,8 @@ for b, iters in ((64, 3000), (256, 1000), (1024, 300)):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / iters * 1e3)
     res[b] = best
+    if b == 256:  # lets two variants be compared beyond the B = 64 goldens
+        res["sum256"] = f"{float(v3.double().abs().sum()):.6e}/{float(pr.double().abs().sum()):.6e}/{int(lp.long().sum())}"
     if b == 64:
         sub = g["b64_subset"]
         ev = float(np.abs(v3.cpu().numpy()[:, sub] - g["b64_v3d_sub"]).max()); ep = float(np.abs(pr.cpu().numpy()[:, sub] - g["b64_proj_sub"]).max())
@@ -48,4 +50,4 @@ for b, iters in ((64, 3000), (256, 1000), (1024, 300)):
         res["golden"] = f"{'OK' if ok else 'MISMATCH'} dv={ev:.1e} dp={ep:.1e} lmk_diff={int(d.sum())}"
 n = C.c_uint()
 _lib.check(lib.dad3d_flame_handoff_timeouts(hm.flame._handle, C.byref(n)))
-print(f"AB {tag:28s} B64 {res[64]:6.2f} us  B256 {res[256]:6.2f} us  B1024 {res[1024]:7.2f} us  golden {res['golden']}  timeouts {n.value}", flush=True)
+print(f"AB {tag:28s} B64 {res[64]:6.2f} us  B128 {res[128]:6.2f} us  B256 {res[256]:6.2f} us  B1024 {res[1024]:7.2f} us  golden {res['golden']}  sum256 {res['sum256']}  timeouts {n.value}", flush=True)
