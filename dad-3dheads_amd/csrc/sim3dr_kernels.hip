@@ -579,9 +579,15 @@ struct TriLane {  // one triangle as a lane carries it: setup, corner depths, bo
 
 // exact n / d and n % d for 0 <= n <= 512, 1 <= d <= 64: (n + 0.5) / d is at least 0.5 / d away from an integer,
 // far more than the relative 1e-7 of v_rcp_f32 on a quotient below 513
-__device__ __forceinline__ void divmod_small(int n, int d, int& q, int& r) {
-    q = (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+__device__ __forceinline__ void divmod_small(int n, int d, float rcp_d, int& q, int& r) {  // rcp_d = v_rcp_f32(d)
+    q = (int)(((float)n + 0.5f) * rcp_d);
     r = n - q * d;
+}
+
+// orderable(z) for a z that is not NaN: one shift, one or, one xor
+__device__ __forceinline__ unsigned depth_order_number(float z) {
+    const int u = __float_as_int(z + 0.0f);  // -0 -> +0
+    return (unsigned)u ^ ((unsigned)(u >> 31) | 0x80000000u);
 }
 
 // MODE 0: _rasterize (strictly-interior test, colour output)   MODE 1: _rasterize_triangles
@@ -760,14 +766,25 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
                 t.bx0 = max((int)(bbx & 0xffff), tx0);
                 t.by0 = max((int)(bby & 0xffff), ty0);
                 const int bw = min((int)(bbx >> 16), tx1) - t.bx0 + 1, bh = min((int)(bby >> 16), ty1) - t.by0 + 1;
-                const int area = bw * bh, g = 1 << cur.lg;
+                // The lane's pixels are box entries sub, sub + g, ... (row-major). Their coordinates are carried as floats
+                // (exact: integers below 2^16) so that a step is two adds and a wrap, and the walk ends when the row
+                // index reaches the box height (index < area <=> row < bh).
+                const int g = 1 << cur.lg;
                 int x, y, gq, gr;
-                divmod_small(cur.sub, bw, y, x);
-                divmod_small(g, bw, gq, gr);
-                for (int j = cur.sub; j < area; j += g) {
-                    pixel(t, t.bx0 + x, t.by0 + y);
-                    y += gq, x += gr;
-                    if (x >= bw) x -= bw, ++y;
+                if (cur.lg == 0) {  // wave-uniform: one lane per triangle, entry 0, stride 1
+                    x = 0, y = 0, gq = bw == 1 ? 1 : 0, gr = bw == 1 ? 0 : 1;
+                } else {
+                    const float rcp_bw = __builtin_amdgcn_rcpf((float)bw);
+                    divmod_small(cur.sub, bw, rcp_bw, y, x);
+                    divmod_small(g, bw, rcp_bw, gq, gr);
+                }
+                float px = (float)(t.bx0 + x), py = (float)(t.by0 + y);
+                const float fgr = (float)gr, fgq = (float)gq, fbw = (float)bw;
+                const float x_end = (float)(t.bx0 + bw), y_end = (float)(t.by0 + bh);
+                while (py < y_end) {
+                    pixel(t, px, py);
+                    px += fgr, py += fgq;
+                    if (px >= x_end) px -= fbw, py += 1.0f;
                     if (a.trace) ++d_trips;
                 }
             }
@@ -785,17 +802,20 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     };
 
     // (B) one pixel test: identical arithmetic whichever lane runs it (get_point_weight / is_point_in_tri)
-    auto fragment = [&](const TriLane& t, int x, int y) {
+    const float key_origin = (float)(ty0 * kTile + tx0);
+    auto fragment = [&](const TriLane& t, float px, float py) {
         float u, v;
-        tri_uv(t.ts, (float)x, (float)y, u, v);
+        tri_uv(t.ts, px, py, u, v);
         const float w0 = 1.0f - u - v;
         const bool inside = (MODE == 0) ? (u > 0.0f && v > 0.0f && w0 > 0.0f) : (u >= 0.0f && v >= 0.0f && (u + v < 1.0f));
         if (!inside) return;
         const float z = w0 * t.z0 + v * t.z1 + u * t.z2;
         if (z != z) return;  // NaN never passes `>`
-        const unsigned long long key = ((unsigned long long)depth_order(z) << 32) | (0xFFFFFFFEu - (unsigned)t.f);
+        const unsigned long long key = ((unsigned long long)depth_order_number(z) << 32) | (0xFFFFFFFEu - (unsigned)t.f);
+        // key slot (y - ty0) * 64 + (x - tx0): address arithmetic on exact small integers, one fma and one conversion
+        const int slot = (int)(__builtin_fmaf(py, (float)kTile, px) - key_origin);
         // fire-and-forget ds_max_u64: no returned value, so the wave never waits on the LDS round trip
-        (void)__hip_atomic_fetch_max(&keys[(y - ty0) * kTile + (x - tx0)], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_max(&keys[slot], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     const int nrounds = (n_total + kListCap - 1) / kListCap;  // 1 for a head mesh: the list is sorted once

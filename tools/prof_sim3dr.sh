@@ -8,11 +8,12 @@ for v in "$@"; do
   f=$(find /tmp/ps_$v -name "*kernel_stats.csv" | head -1)
   echo "== $v: $(grep AB3D /tmp/ps_$v.log | sed 's/.*normals_exact/normals_exact/')"
   python3 - "$f" <<'PY'
-import csv, sys
+import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
     if "dad3d" in n and "flame_decode" not in n:
-        short = n.split("dad3d::")[-1].split("(")[0][:60]
+        m = re.search(r"(\w+(<[^(]*>)?)\(", n.replace("(anonymous namespace)::", ""))
+        short = (m.group(1) if m else n)[:60]
         print(f"   {short:62s} calls {r['Calls']:>5s}  avg {float(r['AverageNs'])/1e3:7.2f} us")
 PY
 done
