@@ -446,6 +446,9 @@ __device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned*
     }
 }
 
+#ifndef DAD3D_RK_ABLATE  // diagnostics only: 1 no fragment walk, 2 no resolve, 4 resolve without colour gathers, 8 without records
+#define DAD3D_RK_ABLATE 0
+#endif
 #ifndef DAD3D_K1_ABLATE  // diagnostics only (tools/k1_ablate.sh): 1 no LDS binning atomics, 2 no list writes, 4 no records
 #define DAD3D_K1_ABLATE 0
 #endif
@@ -602,6 +605,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     __shared__ int cbase[kClasses + 1];           // first slist entry of a class
     __shared__ int sbase[kClasses + 1];           // first lane slot of a class (multiples of 64)
     __shared__ unsigned s_item;
+    __shared__ uint2 s_qe;
     __shared__ int step_ctr;                      // next 64-lane step of the walk to hand to a wave
     unsigned* kw = reinterpret_cast<unsigned*>(keys);  // kw[2p] = ~triangle (low word), kw[2p+1] = depth
     const int tid = threadIdx.x, lane = tid & 63;
@@ -609,17 +613,18 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     const size_t nt = a.m.ntri;
     const unsigned n_items = a.sc.qhdr[0];
 
+    // A workgroup's first item is its own index (no counter: 512 same-address atomics at the start of the launch cost
+    // every first-round item microseconds); later ones are claimed from the counter (which counts the claims beyond the
+    // grid) by thread 0 when the walk is over, so that the round trip hides under the resolve.
+    unsigned item = blockIdx.x;
+    uint2 qe = item < n_items ? a.sc.queue[item] : make_uint2(0u, 0u);
     for (;;) {
-    if (tid == 0) s_item = atomicAdd(&a.sc.qhdr[1], 1u);
-    __syncthreads();
-    const unsigned item = s_item;
     if (item >= n_items) break;
-    const uint2 qe = a.sc.queue[item];
     const int level = (qe.x >> 24) & 3, part = qe.x >> 26, n_total = (int)qe.y;
     const size_t b = (qe.x & 0xFFFFFFu) / ntiles;
     const int tile = (qe.x & 0xFFFFFFu) % ntiles;
     // the item's pixel rectangle: the whole tile or one of its 2x2 / 4x4 parts
-    const int edge = kTile >> level;
+    const int edge = kTile >> level, edge_shift = kTileShift - level;  // 64, 32 or 16 pixels: rows by shifts, not divisions
     const int tx0 = (tile % a.sc.tiles_x) * kTile + (part & ((1 << level) - 1)) * edge;
     const int ty0 = (tile / a.sc.tiles_x) * kTile + (part >> level) * edge;
     const int tw = min(edge, a.w - tx0), th = min(edge, a.h - ty0);
@@ -633,8 +638,15 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     stamp(0);
     if (tw > 0 && th > 0) {  // a part can lie beyond the image edge
 
+    // the first kListCap list entries are requested before the keys are initialised: one memory round trip less in line
+    unsigned first_entries[kListPerThread];
+#pragma unroll
+    for (int k = 0; k < kListPerThread; ++k) {
+        const int i = k * kRasterThreads + tid;
+        first_entries[k] = i < min(kListCap, n_total) ? glist[i] : ~0u;
+    }
     for (int p = tid; p < edge * th; p += kRasterThreads) {
-        const int ly = p / edge, lx = p - ly * edge;
+        const int ly = p >> edge_shift, lx = p & (edge - 1);
         if (lx >= tw) continue;
         const float z0 = depth_b ? depth_b[(size_t)(ty0 + ly) * a.w + tx0 + lx] : -1e8f;  // Sim3DR.py:23
         keys[ly * kTile + lx] = ((unsigned long long)depth_order(z0) << 32) | kNoTri;
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
         for (int k = 0; k < kListPerThread; ++k) {
             const int i = k * kRasterThreads + tid;
             cl[k] = -1;
-            const unsigned e = i < n ? glist[r * kListCap + i] : ~0u;
+            const unsigned e = r == 0 ? first_entries[k] : i < n ? glist[r * kListCap + i] : ~0u;
             if (e != ~0u) {
                 fv[k] = e & kIdMask;
                 cl[k] = (int)(e >> 28);
@@ -717,15 +729,13 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
         bool valid;
     };
     auto walk = [&](int trace_base, auto&& pixel) {
-        int sb[kClasses + 1];
-#pragma unroll
-        for (int c = 0; c <= kClasses; ++c) sb[c] = __builtin_amdgcn_readfirstlane(sbase[c]);
+        const int n_slots = __builtin_amdgcn_readfirstlane(sbase[kClasses]);
+        // lane k - 1 keeps the first slot of class k: the class of a wave step is a ballot and a population count
+        const int class_start = (lane < kClasses - 1) ? sbase[lane + 1] : INT_MAX;
         auto fetch = [&](int s0, Slot& sl) {  // s0 is wave-uniform
             sl.valid = false;
-            if (s0 >= sb[kClasses]) return;
-            int c = 0;
-#pragma unroll
-            for (int k = 1; k < kClasses; ++k) c += (s0 >= sb[k]) ? 1 : 0;
+            if (s0 >= n_slots) return;
+            const int c = __builtin_popcountll(__ballot(s0 >= class_start));
             sl.lg = max(c - 2, 0);
             const int local = s0 + lane - sbase[c];
             const int ti = local >> sl.lg;
@@ -743,13 +753,8 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             if (lane == 0) st = atomicAdd(&step_ctr, 1);
             return __builtin_amdgcn_readfirstlane(st) * 64;
         };
-        Slot cur, nxt;
-        int s0 = next_step();
-        fetch(s0, cur);
         unsigned d_steps = 0, d_wait = 0, d_work = 0, d_trips = 0;  // diagnostics (a.trace only)
-        while (s0 < sb[kClasses]) {
-            s0 = next_step();
-            fetch(s0, nxt);
+        auto work = [&](const Slot& cur) {
             unsigned c0 = 0, c1 = 0;
             if (a.trace) {
                 c0 = (unsigned)wall_clock64();
@@ -789,7 +794,20 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
                 }
             }
             if (a.trace) d_work += (unsigned)wall_clock64() - c1;
-            cur = nxt;
+        };
+        // two slots used alternately (the record of the next step is in flight while the current one is worked on):
+        // no register copies between steps
+        Slot even, odd;
+        int s0 = next_step();
+        fetch(s0, even);
+        while (s0 < n_slots) {
+            s0 = next_step();
+            fetch(s0, odd);
+            work(even);
+            if (s0 >= n_slots) break;
+            s0 = next_step();
+            fetch(s0, even);
+            work(odd);
         }
         if (a.trace) {
             unsigned mx = d_trips;
@@ -822,12 +840,27 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     for (int r = 0; r < nrounds; ++r) {
         sort_round(r);  // its first barrier also orders the key initialisation before the atomics
         if (r == 0) stamp(1);
-        walk(8, fragment);
+        if (!(DAD3D_RK_ABLATE & 1)) walk(8, fragment);
         if (nrounds > 1) __syncthreads();
     }
     stamp(2);
     __syncthreads();
     stamp(3);
+    }  // part inside the image
+    unsigned claimed = 0;
+    uint2 next_qe = make_uint2(0u, 0u);
+    bool have_next = false;
+    if (tid == 0) claimed = atomicAdd(&a.sc.qhdr[1], 1u);
+    // thread 0, once the counter's answer is back (it is older than the loads of the resolve's first iteration): the
+    // queue entry of the next item, so that the next item starts without a memory round trip of its own
+    auto fetch_next_entry = [&]() {
+        if (tid == 0 && !have_next) {
+            const unsigned nxt = gridDim.x + claimed;
+            if (nxt < n_items) next_qe = a.sc.queue[nxt];
+            have_next = true;
+        }
+    };
+    if (tw > 0 && th > 0) {
 
     // (C) resolve: every pixel is shaded once from the record of its winning triangle. A lane owns one pixel, the
     // lanes of a wave a run of one row: neighbours mostly share the triangle, so their record / index / colour loads
@@ -845,14 +878,32 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
         constexpr int NP = 2;  // pixels per lane in flight
         const int nc = C ? C : a.c;
         const int npix = edge * th;
-        for (int p0 = tid; p0 < npix; p0 += NP * kRasterThreads) {
+        // A lane's pixels are p = tid + k * 512, k < 8. The corner indices of ALL its winning triangles are requested up
+        // front (one round trip), so that an iteration below asks for its records AND its colours together: five dependent
+        // round trips per item instead of eight -- the resolve is bound by their latency, not by the texture unit's rate.
+        constexpr int kPixPerLane = kTile * kTile / kRasterThreads;
+        int3u corners[kPixPerLane];
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < kPixPerLane; ++k) {
+                const int p = tid + k * kRasterThreads;
+                const int py = p >> edge_shift, px = p & (edge - 1);
+                const unsigned lo = (p < npix && px < tw) ? kw[2 * (py * kTile + px)] : kNoTri;
+                corners[k] = *reinterpret_cast<const int3u*>(a.m.tri + 3 * (size_t)(lo != kNoTri ? 0xFFFFFFFEu - lo : 0u));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kPixPerLane / NP; ++it) {
+            const int p0 = tid + it * NP * kRasterThreads;
+            if (p0 >= npix) break;
+            if (it == 1) fetch_next_entry();
             int lx[NP], ly[NP];
             unsigned f[NP];
             bool hit[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = p0 + k * kRasterThreads;
-                ly[k] = p / edge, lx[k] = p - ly[k] * edge;
+                ly[k] = p >> edge_shift, lx[k] = p & (edge - 1);
                 const unsigned lo = (p < npix && lx[k] < tw) ? kw[2 * (ly[k] * kTile + lx[k])] : kNoTri;
                 hit[k] = lo != kNoTri;  // kNoTri: nothing beat the incoming depth, the pixel stays untouched
                 f[k] = hit[k] ? 0xFFFFFFFEu - lo : 0u;
@@ -864,30 +915,24 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const float4* rp = rec_b + (size_t)f[k] * kRecF4;
-                r0[k] = rp[0], r1[k] = rp[1], z1[k] = rp[2].x, z2[k] = rp[2].y;
-                if (MODE == 0) {  // one 12-byte gather (4-byte aligned) instead of three
-                    const int3u t3 = *reinterpret_cast<const int3u*>(a.m.tri + 3 * (size_t)f[k]);
-                    i0[k] = t3.x, i1[k] = t3.y, i2[k] = t3.z;
+                if (DAD3D_RK_ABLATE & 8) {
+                    r0[k] = make_float4(1.f, 2.f, 3.f, (float)f[k]), r1[k] = make_float4(4.f, 5.f, 0.01f, 0.5f), z1[k] = 0.25f, z2[k] = 0.75f;
+                } else {
+                    r0[k] = rp[0], r1[k] = rp[1], z1[k] = rp[2].x, z2[k] = rp[2].y;
                 }
+                if (MODE == 0) i0[k] = corners[it * NP + k].x, i1[k] = corners[it * NP + k].y, i2[k] = corners[it * NP + k].z;
             }
-            float u[NP], v[NP], w0[NP], z[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const TriSetup ts = setup_from_record(r0[k], r1[k]);
-                tri_uv(ts, (float)(tx0 + lx[k]), (float)(ty0 + ly[k]), u[k], v[k]);
-                w0[k] = 1.0f - u[k] - v[k];
-                z[k] = w0[k] * r1[k].w + v[k] * z1[k] + u[k] * z2[k];
-            }
-            // the records are dead from here on: only now ask for the colours
-            __builtin_amdgcn_sched_barrier(0);
             float col[NP][3 * CC];
             if (packed) {
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     if (C == 3) {  // a corner's colour is 12 contiguous bytes: one gather per corner
-                        const float3u q0 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i0[k]);
-                        const float3u q1 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i1[k]);
-                        const float3u q2 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i2[k]);
+                        float3u q0 = {0.1f, 0.2f, 0.3f}, q1 = {0.4f, 0.5f, 0.6f}, q2 = {0.7f, 0.8f, 0.9f};
+                        if (!(DAD3D_RK_ABLATE & 4)) {
+                            q0 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i0[k]);
+                            q1 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i1[k]);
+                            q2 = *reinterpret_cast<const float3u*>(cb_ + 3 * (size_t)i2[k]);
+                        }
                         col[k][0] = q0.x, col[k][1] = q0.y, col[k][2] = q0.z;
                         col[k][C] = q1.x, col[k][C + 1] = q1.y, col[k][C + 2] = q1.z;
                         col[k][2 * C] = q2.x, col[k][2 * C + 1] = q2.y, col[k][2 * C + 2] = q2.z;
@@ -897,6 +942,14 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
                             col[k][ch] = cb_[C * i0[k] + ch], col[k][C + ch] = cb_[C * i1[k] + ch], col[k][2 * C + ch] = cb_[C * i2[k] + ch];
                     }
                 }
+            }
+            float u[NP], v[NP], w0[NP], z[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const TriSetup ts = setup_from_record(r0[k], r1[k]);
+                tri_uv(ts, (float)(tx0 + lx[k]), (float)(ty0 + ly[k]), u[k], v[k]);
+                w0[k] = 1.0f - u[k] - v[k];
+                z[k] = w0[k] * r1[k].w + v[k] * z1[k] + u[k] * z2[k];
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
@@ -936,7 +989,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
         // the quad is partly covered
         const int qrow = edge / 4;
         for (int q = tid; q < qrow * th; q += kRasterThreads) {
-            const int ly = q / qrow, lx0 = (q - ly * qrow) * 4;
+            const int ly = q >> (edge_shift - 2), lx0 = (q & (qrow - 1)) * 4;
             if (lx0 >= tw) continue;
             const uint4 k01 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0)]);
             const uint4 k23 = *reinterpret_cast<const uint4*>(&kw[2 * (ly * kTile + lx0) + 4]);
@@ -965,7 +1018,8 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
     };
     {
         const bool can_pack = MODE == 0 && (a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.image) & 3) == 0;
-        if (can_pack && a.c == 3) resolve(std::integral_constant<int, 3>{});
+        if (DAD3D_RK_ABLATE & 2) {
+        } else if (can_pack && a.c == 3) resolve(std::integral_constant<int, 3>{});
         else if (can_pack && a.c == 4) resolve(std::integral_constant<int, 4>{});
         else resolve(std::integral_constant<int, 0>{});
     }
@@ -975,7 +1029,10 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
         unsigned long long* tr = a.trace + (size_t)item * kRasterWaves * 16;
         tr[5] = qe.x, tr[6] = n_items, tr[7] = n_total;
     }
-    __syncthreads();  // keys, slist and s_item are reused by the next item
+    fetch_next_entry();
+    if (tid == 0) s_item = gridDim.x + claimed, s_qe = next_qe;
+    __syncthreads();  // keys and slist are reused by the next item; s_item and s_qe are published
+    item = s_item, qe = s_qe;
     }
 }
 
