@@ -878,13 +878,9 @@ static dad3d_status launch_decode_e(const DecodeArgs& a, hipStream_t s) {
 
 template <int KG, bool JAW_ONLY, bool CONTIG>
 static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
-    if (a.posed) {  // training forward: one instantiation (host epoch, four row blocks) that also stores v_posed
-        if (a.flags & kDeviceEpoch) {
-            set_error("dad3d_flame_decode_posed cannot be captured into a graph");
-            return DAD3D_E_UNSUPPORTED;
-        }
-        return launch_decode_r<KG, JAW_ONLY, CONTIG, false, 4, true>(a, s);
-    }
+    if (a.posed)  // training forward: four row blocks whatever the batch, v_posed stored as well
+        return (a.flags & kDeviceEpoch) ? launch_decode_r<KG, JAW_ONLY, CONTIG, true, 4, true>(a, s)
+                                        : launch_decode_r<KG, JAW_ONLY, CONTIG, false, 4, true>(a, s);
     return (a.flags & kDeviceEpoch) ? launch_decode_e<KG, JAW_ONLY, CONTIG, true>(a, s)
                                     : launch_decode_e<KG, JAW_ONLY, CONTIG, false>(a, s);
 }

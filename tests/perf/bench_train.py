@@ -67,6 +67,35 @@ def main():
             torch.autograd.backward([v, pr], [gv, gp])
 
         t_step, t_dec = gpu_time(step), gpu_time(decode_only)
+
+        # the same step captured once into a hipGraph (the ~70 launches of the step replayed without host work)
+        static_p = params.clone().requires_grad_(True)
+
+        def graph_body():
+            q = static_p * 1.0
+            v = hm.vertices_3d(q, zero_rotation=True)
+            pr = hm.reprojected_vertices(q, to_2d=True)
+            loss = sum(l1(normalize_to_cube(v[:, i]), normalize_to_cube(tgt3[:, i])) * w for w, i in zip(*regions))
+            loss = loss + sum(l1(pr[:, i], tgt2[:, i]) * w for w, i in zip(*regions)) * 1e-2
+            loss.backward()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                static_p.grad = None
+                graph_body()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        static_p.grad = None
+        with torch.cuda.graph(graph):
+            graph_body()
+        t_graph = gpu_time(graph.replay)
+        step()  # eager gradient of the same parameters
+        g_eager = step()
+        graph.replay()
+        torch.cuda.synchronize()
+        graph_err = float((static_p.grad - g_eager).abs().max() / g_eager.abs().max())
         # pieces of one backward pass
         layer = hm.flame
         tables = layer.decode_tables()
@@ -91,6 +120,8 @@ def main():
         out[f"b{b}"] = {
             "losses_fwd_bwd_us": t_step * 1e6, "images_per_s": b / t_step,
             "two_decodes_fwd_bwd_us": t_dec * 1e6,
+            "losses_fwd_bwd_hipgraph_us": t_graph * 1e6, "images_per_s_hipgraph": b / t_graph,
+            "hipgraph_vs_eager_grad_rel_err": graph_err,
             "forward_launch_us": {"3d_vertices + v_posed saved": t_fwd * 1e6, "3d_vertices only (inference)": t_fwd0 * 1e6},
             "backward_pieces_us": {"pose_chain": t_chain * 1e6, "vertex_backward": t_vert * 1e6,
                                    "gemm_grad_inputs(rocBLAS)": t_gemm2 * 1e6, "pose_chain_vjp": t_vjp * 1e6},

@@ -205,3 +205,49 @@ def test_full_pose_and_narrow_layout_gradients_match_oracle(flame_model, flame_c
         p = params.clone().cuda().requires_grad_(True)
         (mesh.reprojected_vertices(p * 1.0, to_2d=False) * w.cuda()).sum().backward()
         assert close(p.grad, p_ref.grad)
+
+
+def test_training_step_replays_from_a_hip_graph(hm, flame_consts):
+    """Forward and backward of both mesh terms on one prediction tensor, captured ONCE into a hipGraph and replayed on new
+    parameters: the captured forward runs the device-epoch instantiation of the training kernel (no per-launch argument),
+    and the replays must give the gradients the eager step gives -- and the oracle's."""
+    batch = 6
+    gen = torch.Generator().manual_seed(8)
+    wv, wp = torch.randn((batch, 5023, 3), generator=gen).cuda(), torch.randn((batch, 5023, 2), generator=gen).cuda()
+
+    def backward_of(p):
+        q = p * 1.0
+        v = hm.vertices_3d(q, zero_rotation=True)
+        pr = hm.reprojected_vertices(q)
+        ((v * wv).sum() + (pr * wp).sum() * 1e-2).backward()
+
+    static_p = torch.from_numpy(synthetic.synthetic_params(batch, seed=50)).cuda().requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):  # rocBLAS workspace, the library's partial-sum buffer, autograd's buffers: before the capture
+            static_p.grad = None
+            backward_of(static_p)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    static_p.grad = None
+    with torch.cuda.graph(graph):
+        backward_of(static_p)
+    for seed in (51, 52, 53):
+        params = torch.from_numpy(synthetic.synthetic_params(batch, seed=seed))
+        with torch.no_grad():
+            static_p.copy_(params.cuda())
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = static_p.grad.clone()
+        p = params.clone().cuda().requires_grad_(True)
+        backward_of(p)
+        assert close(replayed, p.grad)
+        p_ref = params.clone().requires_grad_(True)
+        q_ref = p_ref * 1.0
+        ((flame_ref.vertices_3d(flame_consts, q_ref, zero_rotation=True) * wv.cpu()).sum()
+         + (flame_ref.reprojected_vertices(flame_consts, q_ref) * wp.cpu()).sum() * 1e-2).backward()
+        assert close(replayed, p_ref.grad)
+    n = C.c_uint()
+    _lib.check(hm.flame._lib.dad3d_flame_handoff_timeouts(hm.flame._handle, C.byref(n)))
+    assert n.value == 0
