@@ -700,6 +700,41 @@ dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_si
                              static_cast<hipStream_t>(stream));
 }
 
+dad3d_status dad3d_cube_region_loss(const float* pred, const float* target, int batch, int n_verts,
+                                    const int32_t* region_ptr, const int32_t* region_idx, const float* region_weight,
+                                    int n_regions, const int32_t* vert_ptr, const int32_t* vert_region,
+                                    const int32_t* vert_pos, int criterion, float* stats, float* loss_terms,
+                                    float* grad_pred, int device, void* stream) {
+    DAD3D_REQUIRE(batch >= 0 && n_verts >= 0 && n_regions >= 0, "dad3d_cube_region_loss: negative size");
+    DAD3D_REQUIRE(criterion >= DAD3D_LOSS_L1 && criterion <= DAD3D_LOSS_SMOOTH_L1, "dad3d_cube_region_loss: unknown criterion %d", criterion);
+    if (batch == 0 || n_regions == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(pred && target && region_ptr && region_idx && region_weight && stats && loss_terms,
+                  "dad3d_cube_region_loss: null argument");
+    DAD3D_REQUIRE(!grad_pred || (vert_ptr && vert_region && vert_pos), "dad3d_cube_region_loss: the gradient needs the vertex incidence list");
+    DAD3D_REQUIRE(batch <= 65535 && n_regions <= 65535, "dad3d_cube_region_loss: batch / regions beyond the launch grid");
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    CubeLossArgs a{pred, target, region_ptr, region_idx, region_weight, vert_ptr, vert_region, vert_pos, stats, loss_terms,
+                   grad_pred, batch, n_verts, n_regions, criterion};
+    return launch_cube_loss(a, static_cast<hipStream_t>(stream));
+}
+
+int dad3d_point_loss_terms(int n_points) { return point_loss_blocks(n_points); }
+
+dad3d_status dad3d_weighted_point_loss(const float* pred, const float* target, int batch, int n_points, int comps,
+                                       const float* point_weight, float scale, int criterion, float* loss_terms,
+                                       float* grad_pred, int device, void* stream) {
+    DAD3D_REQUIRE(batch >= 0 && n_points >= 0 && comps > 0, "dad3d_weighted_point_loss: bad size");
+    DAD3D_REQUIRE(criterion >= DAD3D_LOSS_L1 && criterion <= DAD3D_LOSS_SMOOTH_L1, "dad3d_weighted_point_loss: unknown criterion %d", criterion);
+    if (batch == 0 || n_points == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(pred && target && point_weight && loss_terms, "dad3d_weighted_point_loss: null argument");
+    DAD3D_REQUIRE(batch <= 65535, "dad3d_weighted_point_loss: batch beyond the launch grid");
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    PointLossArgs a{pred, target, point_weight, loss_terms, grad_pred, scale, batch, n_points, comps, criterion};
+    return launch_point_loss(a, static_cast<hipStream_t>(stream));
+}
+
 dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer) {
     DAD3D_REQUIRE(m, "null handle");
     m->d_trace = device_buffer;

@@ -190,6 +190,35 @@ dad3d_status launch_project_vertices(const float* vertices, const float* model_v
                                      const float* frame, int batch, int nver, float* world_homo, float* xy, int32_t* xy_int,
                                      hipStream_t s);
 
+// the reference's mesh losses, value and gradient (mesh_losses.hip)
+constexpr int kCubeStats = 28;  // floats per (region, image): see cube_stats_kernel
+struct CubeLossArgs {
+    const float* pred;           // [B,V,3]
+    const float* target;         // [B,V,3]
+    const int* region_ptr;       // [R+1] offsets into region_idx
+    const int* region_idx;       // [sum N_r] vertex indices, region after region (duplicates allowed)
+    const float* region_weight;  // [R]
+    const int* vert_ptr;         // [V+1] incidence list vertex -> (region, position in the region), ascending region
+    const int* vert_region;      // [sum N_r]
+    const int* vert_pos;         // [sum N_r]
+    float* stats;                // [R][B][kCubeStats] scratch
+    float* loss_terms;           // [R][B] weighted mean of the region on image b (their sum is the loss)
+    float* grad_pred;            // [B,V,3] dL/dpred, every element written; null: value only
+    int batch, n_verts, n_regions, criterion;
+};
+struct PointLossArgs {
+    const float* pred;          // [B,N,comps]
+    const float* target;        // [B,N,comps]
+    const float* point_weight;  // [N] sum over the regions of w_r * multiplicity / N_r
+    float* loss_terms;          // [B][point_loss_blocks(N)]
+    float* grad_pred;           // [B,N,comps] or null
+    float scale;                // 1 / (B * comps): the rest of the mean
+    int batch, n_points, comps, criterion;
+};
+int point_loss_blocks(int n_points);
+dad3d_status launch_cube_loss(const CubeLossArgs& a, hipStream_t s);
+dad3d_status launch_point_loss(const PointLossArgs& a, hipStream_t s);
+
 // predictor preprocessing (preprocess.hip): descs = [B][8] int64 on the device: {src pointer, h, w, new_h, new_w, pad_top,
 // pad_left, row stride in bytes}
 dad3d_status launch_preprocess(const long long* descs, int batch, int out_size, const float mean[3], const float std[3],

@@ -251,6 +251,32 @@ dad3d_status dad3d_project_vertices(const float* vertices, const float* model_vi
                                     int32_t* xy_int, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The reference's mesh losses, VALUE and GRADIENT w.r.t. the prediction, on vertices that are already in HBM (the outputs of
+ * the differentiable decode). All pointers are DEVICE pointers; nothing is allocated, both calls can be captured into a graph.
+ *
+ * dad3d_cube_region_loss  = Vertices3DLoss.forward after its decode (model_training/losses/vertices_3d_loss.py:43-49):
+ *     sum_r w_r * criterion(normalize_to_cube(pred[:, idx_r]), normalize_to_cube(target[:, idx_r]))
+ *   normalize_to_cube: model_training/model/utils.py:55-68; criterion: nn.L1Loss / MSELoss / SmoothL1Loss, reduction "mean"
+ *   (vertices_3d_loss.py:11). The gradient of a min / max goes to its arg position, as torch autograd routes it.
+ *     region_ptr [R+1], region_idx [sum N_r]  the index lists of indices_reweighing (model_training/utils.py:108-117)
+ *     vert_ptr [V+1], vert_region, vert_pos   the same incidence transposed: for every vertex the (region, position) pairs
+ *     stats [R][B][28] scratch; loss_terms [R][B] (the loss is their sum); grad_pred [B,V,3] or NULL (value only)
+ * dad3d_weighted_point_loss = ReprojectionLoss.forward after its decode (model_training/losses/reprojection_loss.py:42-46):
+ *     sum_r w_r * criterion(pred[:, idx_r], target[:, idx_r]) = sum_{b,n,c} point_weight[n] * scale * criterion(pred - target)
+ *   with point_weight[n] = sum_r w_r * multiplicity_r(n) / N_r and scale = 1 / (B * comps).
+ *     loss_terms [B][dad3d_point_loss_terms(n_points)] (the loss is their sum); grad_pred [B,N,comps] or NULL */
+enum { DAD3D_LOSS_L1 = 0, DAD3D_LOSS_L2 = 1, DAD3D_LOSS_SMOOTH_L1 = 2 };
+dad3d_status dad3d_cube_region_loss(const float* pred, const float* target, int batch, int n_verts,
+                                    const int32_t* region_ptr, const int32_t* region_idx, const float* region_weight,
+                                    int n_regions, const int32_t* vert_ptr, const int32_t* vert_region,
+                                    const int32_t* vert_pos, int criterion, float* stats, float* loss_terms,
+                                    float* grad_pred, int device, void* stream);
+int dad3d_point_loss_terms(int n_points);
+dad3d_status dad3d_weighted_point_loss(const float* pred, const float* target, int batch, int n_points, int comps,
+                                       const float* point_weight, float scale, int criterion, float* loss_terms,
+                                       float* grad_pred, int device, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * FaceMeshPredictor._transform + _array_to_batch (predictor.py:80-95,195-203) for a batch of uint8 RGB images of ANY sizes
  * in one launch: LongestMaxSize (cv2.resize INTER_LINEAR, 8-bit fixed-point path) -> PadIfNeeded (centred, 0) -> Normalize
  * ((x - 255 mean) * (1 / (255 std)), float32) -> CHW. All DEVICE pointers:

@@ -41,20 +41,26 @@ def main():
     hm = HeadMesh(flame_model=model, landmarks=landmarks.canonical("445", st), static=st, device=0)
     regions = ([1.0, 0.5], [torch.arange(0, 5023, 3).cuda(), torch.from_numpy(landmarks.canonical("445", st)).cuda()])
     l1 = torch.nn.L1Loss()
+    from dad_3dheads_amd.losses import RegionTables, _CubeRegionLoss, _WeightedPointLoss  # the modules' fused kernels
+
+    region_tables = RegionTables(regions[0], [i.cpu().numpy() for i in regions[1]], 5023, torch.device("cuda", 0))
     out = {}
     for b in batches:
         params = torch.from_numpy(synthetic.synthetic_params(b, seed=1)).cuda()
         tgt3 = torch.randn((b, 5023, 3), device="cuda")
         tgt2 = torch.randn((b, 5023, 2), device="cuda") * 128 + 128
 
-        def step():
-            p = params.clone().requires_grad_(True)
-            q = p * 1.0
+        def loss_of(q, fused):  # Vertices3DLoss + 1e-2 ReprojectionLoss on one prediction tensor
             v = hm.vertices_3d(q, zero_rotation=True)
             pr = hm.reprojected_vertices(q, to_2d=True)
+            if fused:  # what dad_3dheads_amd.losses.{Vertices3DLoss,ReprojectionLoss} run (csrc/mesh_losses.hip)
+                return _CubeRegionLoss.apply(v, tgt3, region_tables, 0) + _WeightedPointLoss.apply(pr, tgt2, region_tables, 0) * 1e-2
             loss = sum(l1(normalize_to_cube(v[:, i]), normalize_to_cube(tgt3[:, i])) * w for w, i in zip(*regions))
-            loss = loss + sum(l1(pr[:, i], tgt2[:, i]) * w for w, i in zip(*regions)) * 1e-2
-            loss.backward()
+            return loss + sum(l1(pr[:, i], tgt2[:, i]) * w for w, i in zip(*regions)) * 1e-2
+
+        def step(fused=True):
+            p = params.clone().requires_grad_(True)
+            loss_of(p * 1.0, fused).backward()
             return p.grad
 
         gv, gp = torch.randn((b, 5023, 3), device="cuda"), torch.randn((b, 5023, 2), device="cuda")
@@ -67,17 +73,14 @@ def main():
             torch.autograd.backward([v, pr], [gv, gp])
 
         t_step, t_dec = gpu_time(step), gpu_time(decode_only)
+        t_step_torch = gpu_time(lambda: step(False))
+        fused_vs_torch = float((step(True) - step(False)).abs().max() / step(False).abs().max())
 
-        # the same step captured once into a hipGraph (the ~70 launches of the step replayed without host work)
+        # the same step captured once into a hipGraph (its launches replayed without host work)
         static_p = params.clone().requires_grad_(True)
 
         def graph_body():
-            q = static_p * 1.0
-            v = hm.vertices_3d(q, zero_rotation=True)
-            pr = hm.reprojected_vertices(q, to_2d=True)
-            loss = sum(l1(normalize_to_cube(v[:, i]), normalize_to_cube(tgt3[:, i])) * w for w, i in zip(*regions))
-            loss = loss + sum(l1(pr[:, i], tgt2[:, i]) * w for w, i in zip(*regions)) * 1e-2
-            loss.backward()
+            loss_of(static_p * 1.0, True).backward()
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -120,6 +123,7 @@ def main():
         out[f"b{b}"] = {
             "losses_fwd_bwd_us": t_step * 1e6, "images_per_s": b / t_step,
             "two_decodes_fwd_bwd_us": t_dec * 1e6,
+            "losses_fwd_bwd_torch_loss_graph_us": t_step_torch * 1e6, "fused_vs_torch_grad_rel_err": fused_vs_torch,
             "losses_fwd_bwd_hipgraph_us": t_graph * 1e6, "images_per_s_hipgraph": b / t_graph,
             "hipgraph_vs_eager_grad_rel_err": graph_err,
             "forward_launch_us": {"3d_vertices + v_posed saved": t_fwd * 1e6, "3d_vertices only (inference)": t_fwd0 * 1e6},

@@ -251,3 +251,54 @@ def test_training_step_replays_from_a_hip_graph(hm, flame_consts):
     n = C.c_uint()
     _lib.check(hm.flame._lib.dad3d_flame_handoff_timeouts(hm.flame._handle, C.byref(n)))
     assert n.value == 0
+
+
+@pytest.mark.parametrize("crit", ["l1", "l2", "smooth_l1"])
+def test_fused_loss_kernels_match_the_torch_statement(crit):
+    """csrc/mesh_losses.hip against the reference's own formulation through torch (vertices_3d_loss.py:43-49,
+    reprojection_loss.py:42-46, model/utils.py:55-68) on random tensors: overlapping regions, a region that repeats a
+    vertex, a single-vertex-wide region and negative indices; value and dL/d(pred) incl. the arg-position terms of the
+    normalisation."""
+    from dad_3dheads_amd.losses import RegionTables, _CubeRegionLoss, _WeightedPointLoss, _CRITERION_ID
+
+    n_verts, batch = 700, 5
+    rng = np.random.default_rng(17)
+    indices = [np.arange(0, n_verts, 3), rng.permutation(n_verts)[:257], np.array([5, 9, 9, 300, 12, 5, 640]),
+               np.arange(100, 400), np.array([-1, -2, 3, 4])]
+    weights = [1.0, 0.5, 2.0, 0.25, 1.5]
+    fn = {"l1": torch.nn.L1Loss, "l2": torch.nn.MSELoss, "smooth_l1": torch.nn.SmoothL1Loss}[crit]()
+    tables = RegionTables(weights, indices, n_verts, torch.device("cuda", 0))
+    gen = torch.Generator().manual_seed(4)
+    scale = 3.0 if crit == "smooth_l1" else 1.0  # differences on both sides of SmoothL1's knee
+    for comps, fused, stated in (
+            (3, _CubeRegionLoss, lambda p, t: torch.stack([fn(normalize_to_cube(p[:, i]), normalize_to_cube(t[:, i])) * w
+                                                           for w, i in zip(weights, indices)]).sum()),
+            (3, _WeightedPointLoss, lambda p, t: torch.stack([fn(p[:, i], t[:, i]) * w for w, i in zip(weights, indices)]).sum()),
+            (2, _WeightedPointLoss, lambda p, t: torch.stack([fn(p[:, i], t[:, i]) * w for w, i in zip(weights, indices)]).sum())):
+        pred = (torch.randn((batch, n_verts, comps), generator=gen) * scale).cuda()
+        target = (torch.randn((batch, n_verts, comps), generator=gen) * scale).cuda()
+        p_ref = pred.double().requires_grad_(True)  # float64 torch statement
+        want = stated(p_ref, target.double())
+        want.backward()
+        p = pred.clone().requires_grad_(True)
+        got = fused.apply(p, target, tables, _CRITERION_ID[crit])
+        (got * 1.75).backward()
+        assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+        ref_grad = p_ref.grad.float() * 1.75
+        assert float((p.grad - ref_grad).abs().max()) <= 2e-5 * float(ref_grad.abs().max())
+        with torch.no_grad():  # value-only path (no gradient buffer)
+            assert float(fused.apply(pred, target, tables, _CRITERION_ID[crit])) == float(got)
+
+
+def test_fused_loss_argument_errors():
+    lib = _lib.load()
+    buf = torch.zeros((1, 8, 3), device="cuda")
+    assert lib.dad3d_cube_region_loss(None, None, 0, 8, None, None, None, 0, None, None, None, 0, None, None, None, 0, None) == 0
+    st = lib.dad3d_cube_region_loss(buf.data_ptr(), buf.data_ptr(), 1, 8, None, None, None, 1, None, None, None, 0, None, None, None, 0, None)
+    assert st != 0 and b"null argument" in lib.dad3d_last_error()
+    st = lib.dad3d_weighted_point_loss(buf.data_ptr(), buf.data_ptr(), 1, 8, 3, buf.data_ptr(), 1.0, 7, buf.data_ptr(), None, 0, None)
+    assert st != 0 and b"unknown criterion" in lib.dad3d_last_error()
+    with pytest.raises(IndexError):
+        from dad_3dheads_amd.losses import RegionTables
+
+        RegionTables([1.0], [np.array([0, 8])], 8, torch.device("cuda", 0))
