@@ -74,6 +74,7 @@ SIGNATURES = {
     "dad3d_flame_decode": (_I, [_P, _P, _I, _U, _P, _P, _P, _P, _P]),
     "dad3d_flame_decode_posed": (_I, [_P, _P, _I, _U, _P, _P, _P, _P]),
     "dad3d_flame_decode_backward": (_I, [_P, _I, _U, _P, _P, _P, _P, _P, _P, _P]),
+    "dad3d_flame_grad_inputs": (_I, [_P, _P, _I, _P, _P]),
     "dad3d_flame_num_chain_inputs": (_I, [_P]),
     "dad3d_flame_pose_chain": (_I, [_P, _P, _I, _P, _P, _P]),
     "dad3d_flame_pose_chain_backward": (_I, [_P, _P, _I, _P, _P, _P, _P]),

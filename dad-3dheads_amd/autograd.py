@@ -8,15 +8,17 @@ decode (`dad3d_flame_decode`) and the backward pass is split where the sizes spl
   turns dL/d(3d_vertices), dL/d(projected) into dL/d(v_posed) [B,V,3] and the per-image sums dL/d(consts) [B,72];
 * v_posed (the skinning's input) is saved by the forward launch itself (`dad3d_flame_decode_posed`, one more store per
   vertex); the one contraction of the backward pass with the blend-shape basis, dL/d[betas | pose feature] =
-  dL/d(v_posed) @ basis^T, is a plain library GEMM (rocBLAS through `torch.matmul`);
+  dL/d(v_posed) @ basis^T, is `dad3d_flame_grad_inputs` up to batch 96 -- a split-K fp32 MFMA kernel over the 3V axis + a
+  fixed-order reduction, 25 % faster than rocBLAS at the reference's training batch of 64 -- and rocBLAS through
+  `torch.matmul` above (`GRAD_INPUTS_HIP_MAX_BATCH`);
 * the 72 per-image constants (joint transforms, 6-DoF rotation, scale, translation) are a few hundred flops per image
   of Rodrigues / kinematic chain / Gram-Schmidt: `dad3d_flame_pose_chain` evaluates them and
   `dad3d_flame_pose_chain_backward` differentiates them with dual numbers over the same device code (one launch each
   instead of the ~300 small kernels of a torch graph). `pose_chain` below states the same chain with torch ops; the
   tests use it (and torch's autograd over it) to check the two kernels, and on CPU to pin the layout against the oracle.
 
-A backward pass is four launches (+ one that adds partial sums for small batches): chain, per-vertex kernel, GEMM,
-chain VJP.
+A backward pass is five launches (+ one that adds partial sums for small batches): chain, per-vertex kernel, GEMM +
+its reduction, chain VJP.
 
 Formulas restated from the published smplx algorithm (`lbs.py`: batch_rodrigues, batch_rigid_transform) and
 `model_training/model/utils.py:92-101` (rot_mat_from_6dof); checked against the oracle's autograd in the tests.
@@ -33,6 +35,11 @@ from . import _lib
 from .flame import MAX_EXPRESSION, MAX_SHAPE, FlameParams
 
 N_CONSTS = 72  # csrc/common.hpp kBackwardConsts
+# dL/d(v_posed) @ basis^T: the hand-written split-K kernel up to this batch, rocBLAS above. Measured on MI355X
+# (profiles/r02_bench_train.json): 23.7 vs 31.7 us at B = 64 (the reference's training batch, train_stage/flame_landmarks.yaml:10),
+# 34.0 vs 31.9 at 128, 54 vs 46 at 256, 178 vs 122 at 1024 -- every chunk of the 3V axis writes a [B, 512] partial, and that
+# traffic (15 MB per 64 images, written and read back) grows with the batch while the library's tiling does not pay it.
+GRAD_INPUTS_HIP_MAX_BATCH = 96
 
 
 def axis_angle_to_matrix(r: Tensor) -> Tensor:
@@ -185,7 +192,11 @@ class _Decode(torch.autograd.Function):
                 handle, b, ctx.flags, consts.data_ptr(), posed.data_ptr(),
                 g_v3.data_ptr() if g_v3 is not None else None, g_pj.data_ptr() if g_pj is not None else None,
                 g_posed.data_ptr(), g_consts.data_ptr(), stream))
-            g_inputs = g_posed @ tables.basis.T  # [B,436], library GEMM
+            if b <= GRAD_INPUTS_HIP_MAX_BATCH:
+                g_inputs = torch.empty((b, tables.basis.shape[0]), dtype=torch.float32, device=dev)  # [B,436]
+                _lib.check(lib.dad3d_flame_grad_inputs(handle, g_posed.data_ptr(), b, g_inputs.data_ptr(), stream))
+            else:
+                g_inputs = g_posed @ tables.basis.T  # library GEMM: the split-K partials outgrow their gain (see above)
             g_params = torch.empty_like(staged)
             _lib.check(lib.dad3d_flame_pose_chain_backward(handle, staged.data_ptr(), b, g_inputs.data_ptr(),
                                                            g_consts.data_ptr(), g_params.data_ptr(), stream))

@@ -41,9 +41,11 @@ using namespace dad3d;
 struct FlameConsts {
     int device = 0;
     float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
+    float* d_gpack = nullptr;  // basis^T in MFMA fragment order for dad3d_flame_grad_inputs: built by the first training forward
+    std::mutex gpack_mutex;
     ~FlameConsts() {
         DeviceGuard guard(device);
-        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8})
+        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8, (void*)d_gpack})
             if (p) (void)hipFree(p);
     }
 };
@@ -62,6 +64,8 @@ struct dad3d_flame {
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
     float* d_bwd_partials = nullptr;  // [cap][kBackwardMaxSplit][72] scratch of dad3d_flame_decode_backward
     int bwd_cap = 0;
+    float* d_grad_partials = nullptr;  // [chunks][grad_cap][kGradRows] scratch of dad3d_flame_grad_inputs
+    int grad_cap = 0;                  // images, a multiple of kBlockImages
     int n_lmk = 0;
     float* d_imgc = nullptr;
     unsigned* d_sync = nullptr;   // [0] arrival counter, [1] time-out counter; [4], [5], [last]: device-epoch launches
@@ -72,6 +76,46 @@ struct dad3d_flame {
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
 };
+
+static int grad_chunks(const dad3d_flame* h) { return (h->n_verts * 3 + kGradChunk - 1) / kGradChunk; }
+
+// basis^T pack (once per model, shared by forks) and the split-K scratch for `batch` images (per handle)
+static dad3d_status grad_inputs_prepare(dad3d_flame* h, int batch, hipStream_t s) {
+    const int pad = (batch + kBlockImages - 1) / kBlockImages * kBlockImages;
+    const bool need_pack = h->c->d_gpack == nullptr, need_scratch = pad > h->grad_cap;
+    if (!need_pack && !need_scratch) return DAD3D_OK;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
+    DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone,
+                  "the first training step of a handle (and the first at a larger batch) allocates: run it once before capturing a graph");
+    DAD3D_REQUIRE(h->n_betas + 36 <= kGradRows, "dad3d_flame_grad_inputs: %d inputs exceed %d", h->n_betas + 36, kGradRows);
+    if (need_pack) {
+        std::lock_guard<std::mutex> lock(h->c->gpack_mutex);
+        if (!h->c->d_gpack) {
+            float* pack = nullptr;
+            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pack), grad_pack_floats(grad_chunks(h)) * sizeof(float)));
+            GradPackArgs pa{h->c->d_bpack, pack, h->kgroups, h->n_betas, h->n_pose_feats, h->pose_feat_first, h->n_betas + 36,
+                            h->n_verts * 3, grad_chunks(h)};
+            dad3d_status st = launch_grad_pack(pa, nullptr);
+            if (st == DAD3D_OK && hipDeviceSynchronize() != hipSuccess) st = DAD3D_E_HIP;
+            if (st) {
+                (void)hipFree(pack);
+                set_error("building the basis^T pack failed");
+                return st;
+            }
+            h->c->d_gpack = pack;
+        }
+    }
+    if (need_scratch) {
+        DAD3D_HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(h->d_grad_partials);
+        h->d_grad_partials = nullptr;
+        h->grad_cap = 0;
+        DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_grad_partials), (size_t)grad_chunks(h) * pad * kGradRows * sizeof(float)));
+        h->grad_cap = pad;
+    }
+    return DAD3D_OK;
+}
 
 static dad3d_status flame_reserve(dad3d_flame* h, int nbb) {
     if (nbb <= h->cap_nbb) return DAD3D_OK;
@@ -222,7 +266,8 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
 void dad3d_flame_destroy(dad3d_flame* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
-    for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials})
+    for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials,
+                    (void*)h->d_grad_partials})
         if (p) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
@@ -240,6 +285,8 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->d_sync = nullptr;
     h->d_bwd_partials = nullptr;
     h->bwd_cap = 0;
+    h->d_grad_partials = nullptr;
+    h->grad_cap = 0;
     h->arrive_total = 0;
     h->cap_nbb = 0;
     h->profiling = false;
@@ -298,6 +345,10 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     DAD3D_REQUIRE(!((flags & DAD3D_FLIP_Z) && (flags & DAD3D_TO_2D)), "DAD3D_FLIP_Z needs a 3-component projection");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (posed) {  // a training forward: what its backward pass needs exists before any of it can be captured into a graph
+        dad3d_status st = grad_inputs_prepare(h, batch, s);
+        if (st) return st;
+    }
     const int nbb = (batch + kBlockImages - 1) / kBlockImages;
     if (nbb > h->cap_nbb) {
         DAD3D_HIP_TRY(hipDeviceSynchronize());
@@ -462,6 +513,20 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
         ba.partials = h->d_bwd_partials;
     }
     return launch_flame_backward(ba, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, int batch, float* grad_inputs, void* stream) {
+    DAD3D_REQUIRE(h && batch >= 0, "dad3d_flame_grad_inputs: bad argument");
+    if (batch == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(grad_posed && grad_inputs, "dad3d_flame_grad_inputs: null argument");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dad3d_status st = grad_inputs_prepare(h, batch, s);  // a no-op after the training forward of the same batch size
+    if (st) return st;
+    const int pad = (batch + kBlockImages - 1) / kBlockImages * kBlockImages;
+    GradInputsArgs ga{grad_posed, h->c->d_gpack, h->d_grad_partials, grad_inputs, batch, pad, h->n_verts * 3, grad_chunks(h),
+                      h->n_betas + 36};
+    return launch_grad_inputs(ga, s);
 }
 
 static ChainArgs chain_args(const dad3d_flame* h, const float* params, int batch) {

@@ -139,6 +139,27 @@ struct BackwardArgs {
 dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s);
 constexpr int kBackwardMaxSplit = 8;
 
+// dL/d[betas | pose feature] = dL/d(v_posed) . basis^T (flame_backward.hip): split over the 3V axis in chunks of kGradChunk
+constexpr int kGradChunk = 256;        // columns (vertex coordinates) per workgroup
+constexpr int kGradQuarters = 4;       // output quarters: a workgroup's four waves take two 16-row MFMA tiles each
+constexpr int kGradQuarterRows = 128;
+constexpr int kGradRows = kGradQuarters * kGradQuarterRows;    // 512 >= n_betas + 36
+struct GradPackArgs {      // builds the MFMA B-fragment pack of basis^T from the forward pack, once per model
+    const float* bpack;    // forward pack (DecodeArgs::bpack)
+    float* gpack;          // [n_chunks][4 quarters][4 waves][16 groups][2 tiles][64][4]
+    int kgroups, n_betas, n_pose_feats, pose_feat_first, n_inputs, n_cols, n_chunks;
+};
+struct GradInputsArgs {
+    const float* g_posed;  // [B][n_cols]
+    const float* gpack;
+    float* partials;       // [n_chunks][batch_pad][kGradRows]
+    float* g_inputs;       // [B][n_inputs]
+    int batch, batch_pad, n_cols, n_chunks, n_inputs;
+};
+size_t grad_pack_floats(int n_chunks);
+dad3d_status launch_grad_pack(const GradPackArgs& a, hipStream_t s);
+dad3d_status launch_grad_inputs(const GradInputsArgs& a, hipStream_t s);
+
 // Per-image chain (flame_backward.hip): forward writes `inputs` and `consts`; vjp reads g_inputs / g_consts, writes g_params.
 struct ChainArgs {
     const float* params;    // [B,P]

@@ -412,3 +412,189 @@ dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s) {
 }
 
 }  // namespace dad3d
+
+// ------------------------------------------------------------------------------------------------------
+// dL/d[betas | pose feature] = dL/d(v_posed) . basis^T     [B, 3V] x [3V, 436]      (fp32 MFMA, split over the 3V axis)
+// ------------------------------------------------------------------------------------------------------
+// The one contraction of the backward pass with the blend-shape basis (the transpose of the forward GEMM, flame.py:212-221
+// through torch autograd in the reference). The long axis is the contraction: the 3V columns are cut into chunks of 256 and a
+// workgroup owns (chunk, quarter of the outputs: 128 rows, 436 padded to 512). Its four waves take two 16-row tiles each and
+// keep their basis fragments -- all 16 column groups of the chunk, MFMA B-fragment order, built on the device from the
+// forward pack the first time a training forward runs -- in registers for the whole launch, while the workgroup walks the
+// batch in blocks of 64 images: the block's rows of dL/d(v_posed) are staged in LDS ([64][260] floats, ds_read_b128
+// conflict-free, two buffers: the next block is in flight while this one multiplies), 8 accumulator tiles of
+// v_mfma_f32_16x16x4_f32 per wave, stored straight to the chunk's partial [B][512]. A second small launch adds the chunks in
+// chunk order: no atomics, bit-reproducible.
+namespace dad3d {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGradThreads = 512;  // waves 0-3 multiply, waves 4-7 stage the next block of image rows
+constexpr int kGradGroups = kGradChunk / 16;  // 16-column groups per chunk
+constexpr int kGradLd = kGradChunk + 4;       // row stride of the LDS image of dL/d(v_posed): 16 lanes x 16 B hit 16 bank groups
+
+// element (row r of the 436 inputs, column col of the 3V) of the basis, read out of the FORWARD pack
+__device__ __forceinline__ float forward_pack_at(const GradPackArgs& a, int r, int col) {
+    int k = r;
+    if (r >= a.n_betas) {
+        const int p = r - a.n_betas;
+        if (p < a.pose_feat_first || p >= a.pose_feat_first + a.n_pose_feats) return 0.0f;  // a feature that is exactly 0
+        k = a.n_betas + (p - a.pose_feat_first);
+    }
+    const int v = col / 3, comp = col - 3 * v;
+    const int tile = v / kTileVerts, cc = (v - tile * kTileVerts) * 3 + comp;
+    const size_t at = ((((size_t)tile * a.kgroups + (k >> 4)) * 4 + (cc >> 4)) * 64 + ((k >> 2) & 3) * 16 + (cc & 15)) * 4 + (k & 3);
+    return a.bpack[at];
+}
+
+// pack: [chunk][quarter][wave][group g][tile tt of the wave (2)][lane][4]; lane (q, i), step s <-> row = 128 quarter + 32 wave
+// + 16 tt + i, column = 256 chunk + 16 g + 4 q + s
+__global__ void grad_pack_kernel(GradPackArgs a) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the pack
+    const size_t n = (size_t)a.n_chunks * kGradQuarters * 4 * kGradGroups * 2 * 64;
+    if (e >= n) return;
+    const int lane = (int)(e & 63), tt = (int)((e >> 6) & 1);
+    size_t rest = e >> 7;
+    const int g = (int)(rest % kGradGroups);
+    rest /= kGradGroups;
+    const int wave = (int)(rest & 3);
+    rest >>= 2;
+    const int nq = (int)(rest % kGradQuarters), c = (int)(rest / kGradQuarters);
+    const int row = nq * kGradQuarterRows + 32 * wave + 16 * tt + (lane & 15);
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.n_inputs) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = c * kGradChunk + 16 * g + 4 * (lane >> 4) + s;
+            if (col < a.n_cols) out[s] = forward_pack_at(a, row, col);
+        }
+    }
+    reinterpret_cast<f32x4*>(a.gpack)[e] = out;
+}
+
+__global__ __launch_bounds__(kGradThreads) void grad_inputs_kernel(GradInputsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float a_lds[];  // [2][64][kGradLd]
+    const int chunk = blockIdx.x, nq = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, tid = threadIdx.x & 255;
+    const bool feeder = threadIdx.x >= 256;  // wave-uniform
+    const int c0 = chunk * kGradChunk;
+    const int row0 = nq * kGradQuarterRows + 32 * wave;  // this wave's 32 output rows
+    const bool wave_live = !feeder && row0 < a.n_inputs;   // the padding of the last quarter is nobody's work
+    // this wave's basis fragments: resident for the whole launch
+    f32x4 bq[kGradGroups][2];
+    {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(a.gpack) +
+                          ((((size_t)chunk * kGradQuarters + nq) * 4 + wave) * kGradGroups * 2) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < kGradGroups; ++g)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) bq[g][tt] = wave_live ? gp[(size_t)(g * 2 + tt) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int col = c0 + tid;
+    const bool col_ok = col < a.n_cols;
+    const float* src = a.g_posed + min(col, a.n_cols - 1);
+    float stage[kBlockImages];
+    auto request = [&](int img0) {  // all 64 loads of a thread in flight together (clamped addresses, no branch per load)
+#pragma unroll
+        for (int r = 0; r < kBlockImages; ++r) stage[r] = src[(size_t)min(img0 + r, a.batch - 1) * a.n_cols];
+    };
+    auto commit = [&](int img0, float* dst) {  // rows past the batch and columns past 3V are zeros
+#pragma unroll
+        for (int r = 0; r < kBlockImages; ++r) dst[r * kGradLd + tid] = (col_ok && img0 + r < a.batch) ? stage[r] : 0.0f;
+    };
+    if (feeder) {
+        request(0);
+        commit(0, a_lds);
+    }
+    __syncthreads();
+    const int n_blocks = a.batch_pad / kBlockImages;
+    for (int mb = 0; mb < n_blocks; ++mb) {
+        const int img0 = mb * kBlockImages;
+        const float* cur = a_lds + (mb & 1) * kBlockImages * kGradLd;
+        if (feeder && mb + 1 < n_blocks) {  // the next block's rows, while the other four waves multiply this one
+            request(img0 + kBlockImages);
+            commit(img0 + kBlockImages, a_lds + ((mb + 1) & 1) * kBlockImages * kGradLd);
+        }
+        if (wave_live) {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* afrag = cur + (lane & 15) * kGradLd + 4 * (lane >> 4);
+            f32x4 af[4], an[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const f32x4*>(afrag + m * 16 * kGradLd);
+#pragma unroll
+            for (int g = 0; g < kGradGroups; ++g) {
+                if (g + 1 < kGradGroups) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) an[m] = *reinterpret_cast<const f32x4*>(afrag + m * 16 * kGradLd + 16 * (g + 1));
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bq[g][tt][s], acc[m][tt], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = an[m];
+            }
+            // D layout: row (image) = 16m + 4 (lane>>4) + reg, column (output) = 16 tt + (lane&15)
+            float* out = a.partials + ((size_t)chunk * a.batch_pad + img0) * kGradRows + row0 + (lane & 15);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) out[(size_t)(16 * m + 4 * (lane >> 4) + q) * kGradRows + 16 * tt] = acc[m][tt][q];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void grad_inputs_reduce_kernel(GradInputsArgs a) {
+    const int b = blockIdx.x, r = threadIdx.x;
+    if (r >= a.n_inputs) return;
+    float s = 0.0f;
+    const float* src = a.partials + (size_t)b * kGradRows + r;
+    const size_t step = (size_t)a.batch_pad * kGradRows;
+    int c = 0;
+    for (; c + 16 <= a.n_chunks; c += 16) {  // sixteen loads in flight, added in chunk order
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(c + k) * step];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    for (; c < a.n_chunks; ++c) s += src[(size_t)c * step];
+    a.g_inputs[(size_t)b * a.n_inputs + r] = s;
+}
+
+}  // namespace
+
+size_t grad_pack_floats(int n_chunks) { return (size_t)n_chunks * kGradQuarters * 4 * kGradGroups * 2 * 64 * 4; }
+
+dad3d_status launch_grad_pack(const GradPackArgs& a, hipStream_t s) {
+    const size_t n = grad_pack_floats(a.n_chunks) / 4;
+    hipLaunchKernelGGL(grad_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    DAD3D_HIP_TRY(hipGetLastError());
+    return DAD3D_OK;
+}
+
+dad3d_status launch_grad_inputs(const GradInputsArgs& a, hipStream_t s) {
+    static PerDeviceOnce attr_done;
+    const int dev = PerDeviceOnce::current();
+    const size_t lds = (size_t)2 * kBlockImages * kGradLd * sizeof(float);
+    if (!attr_done.done(dev)) {
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_inputs_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done.set(dev);
+    }
+    hipLaunchKernelGGL(grad_inputs_kernel, dim3(a.n_chunks, kGradQuarters), dim3(kGradThreads), lds, s, a);
+    DAD3D_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grad_inputs_reduce_kernel, dim3(a.batch), dim3(kGradRows), 0, s, a);
+    DAD3D_HIP_TRY(hipGetLastError());
+    return DAD3D_OK;
+}
+
+}  // namespace dad3d

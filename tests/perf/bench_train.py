@@ -118,6 +118,7 @@ def main():
         t_vert = gpu_time(lambda: lib.dad3d_flame_decode_backward(h, b, _lib.ZERO_ROTATION, c72.data_ptr(), posed.data_ptr(), gv.data_ptr(),
                                                                   None, g_posed.data_ptr(), g_c.data_ptr(), None))
         t_gemm2 = gpu_time(lambda: torch.matmul(g_posed, tables.basis.T, out=g_in))
+        t_gemm_hip = gpu_time(lambda: lib.dad3d_flame_grad_inputs(h, g_posed.data_ptr(), b, g_in.data_ptr(), None))
         t_vjp = gpu_time(lambda: lib.dad3d_flame_pose_chain_backward(h, params.data_ptr(), b, g_in.data_ptr(), g_c.data_ptr(),
                                                                      g_params.data_ptr(), None))
         out[f"b{b}"] = {
@@ -128,7 +129,8 @@ def main():
             "hipgraph_vs_eager_grad_rel_err": graph_err,
             "forward_launch_us": {"3d_vertices + v_posed saved": t_fwd * 1e6, "3d_vertices only (inference)": t_fwd0 * 1e6},
             "backward_pieces_us": {"pose_chain": t_chain * 1e6, "vertex_backward": t_vert * 1e6,
-                                   "gemm_grad_inputs(rocBLAS)": t_gemm2 * 1e6, "pose_chain_vjp": t_vjp * 1e6},
+                                   "grad_inputs split-K MFMA kernel + reduction (product)": t_gemm_hip * 1e6,
+                                   "grad_inputs through rocBLAS (round 1)": t_gemm2 * 1e6, "pose_chain_vjp": t_vjp * 1e6},
             "vertex_backward_GBps": b * 4 * 60276 / t_vert / 1e9,
         }
     # CPU: torch autograd over the oracle, the reference's way, bounded sample

@@ -302,3 +302,35 @@ def test_fused_loss_argument_errors():
         from dad_3dheads_amd.losses import RegionTables
 
         RegionTables([1.0], [np.array([0, 8])], 8, torch.device("cuda", 0))
+
+
+def test_grad_inputs_kernel_matches_the_plain_contraction(flame_model, static):
+    """`dad3d_flame_grad_inputs` (split-K fp32 MFMA + fixed-order reduction, basis^T packed on the device from the forward
+    pack) against dL/d(v_posed) @ basis^T in float64 with the plain [436, 3V] basis the host keeps, for the three constants
+    layouts (jaw-only 416-row pack, full 448-row pack, narrow shape / expression widths) and ragged batches."""
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(12)
+    for mesh, params_np, consts in _configs(flame_model, static):
+        layer = mesh.flame
+        tables = layer.decode_tables()
+        n_in = lib.dad3d_flame_num_chain_inputs(layer._handle)
+        assert n_in == tables.basis.shape[0]
+        live = torch.ones(n_in, dtype=torch.bool)  # pose features of joints that are not inputs are exactly zero: no gradient
+        if consts["neck"] == 0 and consts["eyeballs"] == 0:
+            live[400:409] = False
+            live[418:436] = False
+        for batch in (1, 5, 64, 70, 130):
+            p = torch.from_numpy(np.resize(params_np, (batch, params_np.shape[1])).astype(np.float32)).cuda()
+            v3 = torch.empty((batch, 5023, 3), device="cuda")
+            posed = torch.empty((batch, 15069), device="cuda")
+            _lib.check(lib.dad3d_flame_decode_posed(layer._handle, p.data_ptr(), batch, 0, v3.data_ptr(), None, posed.data_ptr(), None))
+            g_posed = torch.randn((batch, 15069), generator=gen).cuda()
+            got = torch.full((batch, n_in), float("nan"), device="cuda")
+            _lib.check(lib.dad3d_flame_grad_inputs(layer._handle, g_posed.data_ptr(), batch, got.data_ptr(), None))
+            again = torch.empty_like(got)
+            _lib.check(lib.dad3d_flame_grad_inputs(layer._handle, g_posed.data_ptr(), batch, again.data_ptr(), None))
+            want = (g_posed.double() @ tables.basis.double().T).float()
+            assert torch.equal(got, again)  # no atomics: bit-reproducible
+            err = (got - want)[:, live].abs().max().item()
+            assert err <= 2e-5 * want[:, live].abs().max().item(), (batch, err)
+            assert float(got[:, ~live].abs().max()) == 0.0 if (~live).any() else True
