@@ -36,6 +36,7 @@
 namespace dad3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B load from a 4-byte aligned row
 
@@ -265,6 +266,24 @@ __device__ __forceinline__ void constants_from_joints(const DecodeArgs& a, const
     out[69] = fmaxf(in.scale + 1.0f, 1e-8f);  // head_mesh.py:39
     out[70] = in.tx;
     out[71] = in.ty;  // translation z := 0 (head_mesh.py:41)
+    if (JAW_ONLY) {
+        // The jaw-only epilogue reads NINE float4s laid out for packed fp32 math (v_pk_fma_f32 on (x, y) pairs without
+        // register shuffles); they replace floats [12,48) -- the transforms of the joints that cannot rotate, which that
+        // epilogue never reads (it uses their translations only):
+        //   [12,20) (a00 a10 | a01 a11 | a02 a12 | a03 a13)  rows 0 and 1 of A_jaw, column by column      [20,24) row 2
+        //   [24,32) (t.x t.y) of joints 0, 1, 3, 4                                                        [32,36) their t.z
+        //   [36,42) (R00 R10 | R01 R11 | R02 R12)  [42,44) tx ty    [44,48) R20 R21 R22 s
+        float pk[36];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pk[2 * c] = out[c], pk[2 * c + 1] = out[4 + c], pk[8 + c] = out[8 + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[12 + 2 * q] = out[72 + 3 * q], pk[13 + 2 * q] = out[73 + 3 * q], pk[20 + q] = out[74 + 3 * q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pk[24 + 2 * c] = out[60 + c], pk[25 + 2 * c] = out[63 + c], pk[32 + c] = out[66 + c];
+        pk[30] = out[70], pk[31] = out[71], pk[35] = out[69];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) out[12 + i] = pk[i];
+    }
 }
 
 // this lane's float4 of the betas (lane + 64*pass), zero past the end
@@ -784,18 +803,32 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         const float x = o[0], y = o[1], z = o[2];  // v_posed
         const float4* c4p = reinterpret_cast<const float4*>(imgc + i * kImgConsts);
         float px, py, pz;
+        float rx, ry, rz, ox, oy, sc;
         if (JAW_ONLY) {
             // only the jaw joint rotates: A_j = [I | t_j] for j != 2 (exactly), so
-            // T.[v;1] = S v + w2 (R_jaw v) + sum_j w_j t_j  with S = w0 + w1 + w3 + w4
-            const float4 r0 = c4p[0], r1 = c4p[1], r2 = c4p[2];        // A_2 rows
-            const float4 t01 = c4p[18], t13 = c4p[19], t34 = c4p[20];  // t0 t1 t3 t4 packed
+            // T.[v;1] = S v + w2 (A_jaw [v;1]) + sum_j w_j t_j  with S = w0 + w1 + w3 + w4.
+            // The (x, y) components travel as pairs through v_pk_fma_f32; the constants arrive already paired (see
+            // constants_from_joints), so a vertex costs ~30 VALU instructions instead of ~85.
+            const float4 a01 = c4p[3], a23 = c4p[4], ar2 = c4p[5];  // A_jaw: columns 0,1 | 2,3 of rows 0-1; row 2
+            const float4 t01 = c4p[6], t34 = c4p[7], tz = c4p[8];   // (t.x t.y) of joints 0,1 | 3,4; their t.z
+            const float4 g01 = c4p[9], g2t = c4p[10], g3s = c4p[11];
             const float S = wb.y, w2 = wa.z;
-            const float qx = r0.x * x + r0.y * y + r0.z * z + r0.w;
-            const float qy = r1.x * x + r1.y * y + r1.z * z + r1.w;
-            const float qz = r2.x * x + r2.y * y + r2.z * z + r2.w;
-            px = S * x + w2 * qx + (wa.x * t01.x + wa.y * t01.w + wa.w * t13.z + wb.x * t34.y);
-            py = S * y + w2 * qy + (wa.x * t01.y + wa.y * t13.x + wa.w * t13.w + wb.x * t34.z);
-            pz = S * z + w2 * qz + (wa.x * t01.z + wa.y * t13.y + wa.w * t34.x + wb.x * t34.w);
+            const f32x2 xy = {x, y};
+            f32x2 q = f32x2{a23.z, a23.w} + f32x2{a01.x, a01.y} * x + f32x2{a01.z, a01.w} * y + f32x2{a23.x, a23.y} * z;
+            const float qz = ar2.x * x + ar2.y * y + ar2.z * z + ar2.w;
+            const f32x2 tsum = f32x2{t01.x, t01.y} * wa.x + f32x2{t01.z, t01.w} * wa.y + f32x2{t34.x, t34.y} * wa.w +
+                               f32x2{t34.z, t34.w} * wb.x;
+            const float tsum_z = wa.x * tz.x + wa.y * tz.y + wa.w * tz.z + wb.x * tz.w;
+            const f32x2 p = xy * S + q * w2 + tsum;
+            px = p.x, py = p.y;
+            pz = S * z + w2 * qz + tsum_z + kMeshOffsetZ;  // flame.py:224
+            const f32x2 r = f32x2{g01.x, g01.y} * px + f32x2{g01.z, g01.w} * py + f32x2{g2t.x, g2t.y} * pz;  // flame.py:226-228
+            rx = r.x, ry = r.y;
+            rz = g3s.x * px + g3s.y * py + g3s.z * pz;
+            sc = g3s.w;
+            // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+            const f32x2 o = (r * sc + f32x2{g2t.z, g2t.w} + 1.0f) / 2.0f * a.image_size;
+            ox = o.x, oy = o.y;
         } else {
             // T = sum_j w_j A_j (smplx lbs: W @ A), then T.[v_posed;1]; joint storage order 2,0,1,3,4
             const float wj[kNumJoints] = {wa.z, wa.x, wa.y, wa.w, wb.x};
@@ -813,12 +846,16 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
             px = T[0] * x + T[1] * y + T[2] * z + T[3];
             py = T[4] * x + T[5] * y + T[6] * z + T[7];
             pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+            pz += kMeshOffsetZ;  // flame.py:224
+            const float4 ra = c4p[15], rb = c4p[16], rc = c4p[17];  // R (9) | s tx ty
+            rx = ra.x * px + ra.y * py + ra.z * pz;  // flame.py:226-228
+            ry = ra.w * px + rb.x * py + rb.y * pz;
+            rz = rb.z * px + rb.w * py + rc.x * pz;
+            // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+            sc = rc.y;
+            ox = (rx * sc + rc.z + 1.0f) / 2.0f * a.image_size;
+            oy = (ry * sc + rc.w + 1.0f) / 2.0f * a.image_size;
         }
-        pz += kMeshOffsetZ;  // flame.py:224
-        const float4 ra = c4p[15], rb = c4p[16], rc = c4p[17];  // R (9) | s tx ty
-        const float rx = ra.x * px + ra.y * py + ra.z * pz;  // flame.py:226-228
-        const float ry = ra.w * px + rb.x * py + rb.y * pz;
-        const float rz = rb.z * px + rb.w * py + rc.x * pz;
         const unsigned lv = (unsigned)li * nv + (unsigned)j;  // (image, vertex) relative to the wave's bases
         if (POSED) {  // v_posed is the operand of the backward pass
             float* d = ps_base + lv * 3u;
@@ -830,10 +867,6 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
             d[1] = zero_rot ? py : ry;
             d[2] = zero_rot ? pz : rz;
         }
-        // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
-        const float sc = rc.y;
-        const float ox = (rx * sc + rc.z + 1.0f) / 2.0f * a.image_size;
-        const float oy = (ry * sc + rc.w + 1.0f) / 2.0f * a.image_size;
         if (pj_base) {
             float* d = pj_base + lv * (unsigned)pc;
             d[0] = ox;
