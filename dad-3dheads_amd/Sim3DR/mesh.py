@@ -147,12 +147,13 @@ class Mesh:
         return out
 
     def render(self, vertices: Tensor, bg: Tensor, depth: Optional[Tensor] = None, reverse: bool = False,
-               light_out: Optional[Tensor] = None, ambient: float = 0.3, directional: float = 0.6, specular: float = 0.1,
+               light_out: Optional[Tensor] = None, clear: bool = False, ambient: float = 0.3, directional: float = 0.6, specular: float = 0.1,
                specular_exp: float = 5, color_ambient: Sequence[float] = (1, 1, 1), color_directional: Sequence[float] = (1, 1, 1),
                light_pos: Sequence[float] = (0, 0, 5), view_pos: Sequence[float] = (0, 0, 5)) -> Tensor:
         """RenderPipeline.__call__ (lighting.py:37-71, texture=None) for a batch in TWO launches: the raster's geometry
         kernel also computes normals + Phong light (into `light_out`, allocated when None), the tile kernel rasterises
-        with it into the 3-channel `bg`. Same results as `phong_light(v, None)` followed by `rasterize`."""
+        with it into the 3-channel `bg`. Same results as `phong_light(v, None)` followed by `rasterize`. `clear=True`:
+        `bg` is only a destination, rendered onto black (the geometry launch zeroes it: no fill launch in front)."""
         v = self._verts(vertices)
         img = _chk(bg, torch.uint8, 4, "bg", self.torch_device)
         if img.shape[-1] != 3:
@@ -169,5 +170,6 @@ class Mesh:
                           (C.c_float * 3)(*light_pos), (C.c_float * 3)(*view_pos))
         dptr = None if depth is None else _chk(depth, torch.float32, 3, "depth", self.torch_device).data_ptr()
         _lib.check(self._lib.dad3d_mesh_render(self._handle, img.data_ptr(), v.data_ptr(), light.data_ptr(), dptr, v.shape[0],
-                                               img.shape[1], img.shape[2], C.byref(cfg), int(reverse), self._stream()))
+                                               img.shape[1], img.shape[2], C.byref(cfg), int(bool(reverse)) | (2 if clear else 0),
+                                               self._stream()))
         return img

@@ -720,14 +720,19 @@ dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* ve
 }
 
 dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* vertices, float* light, float* depth, int batch,
-                               int h, int w, const dad3d_light* cfg, int reverse, void* stream) {
+                               int h, int w, const dad3d_light* cfg, int flags, void* stream) {
     DAD3D_REQUIRE(m && cfg && batch >= 0 && h >= 0 && w >= 0, "dad3d_mesh_render: bad argument");
-    if (batch == 0 || h == 0 || w == 0 || m->ntri == 0) return DAD3D_OK;
-    DAD3D_REQUIRE(image && vertices && light, "dad3d_mesh_render: null buffer");
+    if (batch == 0 || h == 0 || w == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(image, "dad3d_mesh_render: null buffer");
     DeviceGuard guard(m->device);
+    if (m->ntri == 0) {  // nothing to draw: only the background
+        if (flags & DAD3D_RENDER_CLEAR) DAD3D_HIP_TRY(hipMemsetAsync(image, 0, (size_t)batch * h * w * 3, static_cast<hipStream_t>(stream)));
+        return DAD3D_OK;
+    }
+    DAD3D_REQUIRE(vertices && light, "dad3d_mesh_render: null buffer");
     if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
     return launch_rasterize(m->dev(), m->d_raster, m->d_trace, image, vertices, light, depth, nullptr, nullptr, batch, h, w, 3,
-                            reverse, 0, cfg, static_cast<hipStream_t>(stream));
+                            flags, 0, cfg, static_cast<hipStream_t>(stream));
 }
 
 dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices, float* depth, int32_t* tri_buf,

@@ -458,6 +458,8 @@ __device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned*
 struct LightJob {
     float* light;  // [B][nver][3]
     dad3d_light cfg;
+    uint4* clear;        // RenderPipeline on a black background: the image buffer, zeroed by this launch (16-byte aligned) ...
+    size_t clear_vec16;  // ... its size in 16-byte units, or 0
 };
 
 template <bool LDS_VERTS, bool WITH_LIGHT>
@@ -472,6 +474,11 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     unsigned* cnt = reinterpret_cast<unsigned*>(lds_v + ((n + 11) & ~3));  // [ntiles] block-local counts, then cursors
     unsigned* asum = cnt + ntiles;                                         // [ntiles] block-local box area sums
     for (int t = tid; t < 2 * ntiles; t += kGeoThreads) cnt[t] = 0;
+    if (WITH_LIGHT && job.clear_vec16) {  // fire-and-forget stores under the staging: no fill launch in front of the render
+        const size_t nblk = (size_t)gridDim.x * gridDim.y, bid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t per = (job.clear_vec16 + nblk - 1) / nblk, end = min(job.clear_vec16, (bid + 1) * per);
+        for (size_t i = bid * per + tid; i < end; i += kGeoThreads) job.clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const float* lv = LDS_VERTS ? stage_floats(lds_v, vb, n, tid) : nullptr;
     __syncthreads();
     if (WITH_LIGHT) {
@@ -1126,8 +1133,9 @@ dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int
 
 dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image,
                               const float* vertices, const float* colors, float* depth, int32_t* tri_buf, float* bary,
-                              int batch, int h, int w, int c, int reverse, int mode, const dad3d_light* light_cfg,
+                              int batch, int h, int w, int c, int render_flags, int mode, const dad3d_light* light_cfg,
                               hipStream_t s) {
+    const int reverse = render_flags & DAD3D_RENDER_REVERSE;
     if (batch == 0 || h == 0 || w == 0 || m.ntri == 0) return DAD3D_OK;  // nothing to draw: buffers stay as they are
     const size_t nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
     DAD3D_REQUIRE(h <= 65535 && w <= 65535 && tiles_of(h) * tiles_of(w) <= kMaxTiles && nlists < (1u << 24),
@@ -1168,6 +1176,15 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
             DAD3D_REQUIRE(vlds <= (size_t)kMaxLds && c == 3 && mode == 0, "render: needs a 3-channel image and a mesh that fits the LDS");
             job.light = const_cast<float*>(colors);
             job.cfg = *light_cfg;
+            if (render_flags & DAD3D_RENDER_CLEAR) {
+                const size_t bytes = (size_t)batch * h * w * c;
+                if ((reinterpret_cast<uintptr_t>(image) & 15) == 0 && (bytes & 15) == 0) {
+                    job.clear = reinterpret_cast<uint4*>(image);
+                    job.clear_vec16 = bytes / 16;
+                } else {
+                    DAD3D_HIP_TRY(hipMemsetAsync(image, 0, bytes, s));
+                }
+            }
             hipLaunchKernelGGL((tri_geometry_kernel<true, true>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
         } else if (vlds <= (size_t)kMaxLds) {
             hipLaunchKernelGGL((tri_geometry_kernel<true, false>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);

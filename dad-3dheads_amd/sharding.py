@@ -99,9 +99,8 @@ class ShardedRenderer:
             self._light_buf = torch.empty((n, self.mesh.nver, 3), dtype=torch.float32, device=dev)
         if n == 0:
             return self._img
-        self._img.zero_()
         verts = self.head_mesh.flame.decode(params_local, proj=True, to_2d=False, flip_z=True, out=self._dec)["proj"]
-        return self.mesh.render(verts, self._img, light_out=self._light_buf, **self.light)
+        return self.mesh.render(verts, self._img, light_out=self._light_buf, clear=True, **self.light)  # black background
 
     def __call__(self, params_global: torch.Tensor) -> torch.Tensor:
         """params_global [B,P] (the same tensor on every rank, or at least this rank's rows valid) -> uint8 [B,h,w,3]

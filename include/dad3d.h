@@ -241,9 +241,12 @@ dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_bu
 /* `RenderPipeline.__call__` with texture=None (Sim3DR/lighting.py:64-71) for a batch, in TWO launches: the geometry kernel
  * of the raster also computes the vertex normals and the Phong light of its share of the vertices (same arithmetic as
  * dad3d_mesh_normal_phong_light) into `light` [B,nver,3], the tile kernel rasterises with `light` as the colours into the
- * 3-channel `image` [B,h,w,3]. `depth` as in dad3d_mesh_rasterize. */
+ * 3-channel `image` [B,h,w,3]. `depth` as in dad3d_mesh_rasterize. `flags`: DAD3D_RENDER_REVERSE = the `reverse` argument of
+ * Sim3DR.rasterize (1, as before); DAD3D_RENDER_CLEAR = render onto a black background (`bg = np.zeros_like(img)`, the
+ * `with_bg_flag=False` call of the reference's demo): the image is zeroed by the geometry launch itself, no fill in front. */
+enum { DAD3D_RENDER_REVERSE = 1, DAD3D_RENDER_CLEAR = 2 };
 dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* vertices, float* light, float* depth, int batch,
-                               int h, int w, const dad3d_light* cfg, int reverse, void* stream);
+                               int h, int w, const dad3d_light* cfg, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Matrix projection of meshes (GT annotations): model_training/data/flame_dataset.py:115-141 (`_load_mesh`,

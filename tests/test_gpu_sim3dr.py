@@ -149,6 +149,15 @@ def test_render_pipeline_matches_numpy_lighting(static, decode_golden, port_orac
     got_light = torch.empty_like(b8)
     got_img = mesh.render(b8, torch.zeros((8, 256, 256, 3), dtype=torch.uint8, device="cuda"), light_out=got_light)
     assert torch.equal(got_light, want_light) and torch.equal(got_img, want_img) and got_img.any()
+    # clear=True: the destination's old contents are irrelevant (the geometry launch zeroes it), also for a buffer that
+    # is not 16-byte aligned / sized (memset path) and with reverse
+    dirty = torch.full((8, 256, 256, 3), 77, dtype=torch.uint8, device="cuda")
+    assert torch.equal(mesh.render(b8, dirty, clear=True), want_img)
+    odd = torch.full((8 * 256 * 256 * 3 + 5,), 99, dtype=torch.uint8, device="cuda")
+    view = odd[5:].view(8, 256, 256, 3)
+    assert torch.equal(mesh.render(b8, view, clear=True), want_img) and int(odd[:5].sum()) == 5 * 99
+    rev = mesh.render(b8, torch.full_like(dirty, 3), reverse=True, clear=True)
+    assert torch.equal(rev, mesh.render(b8, torch.zeros_like(dirty), reverse=True))
     # bytes: identical coverage, and every byte that differs is explained by `(unsigned char)(255 * c)` flipping where the
     # oracle's own float colour is within 255 * 2e-5 of an integer (tests/render_checks.py) -- no tolerance on bytes
     n_diff = assert_render_bytes_explained(img, ref_img, port_oracle, verts, faces, ref_light)
