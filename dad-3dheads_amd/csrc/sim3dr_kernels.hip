@@ -491,12 +491,15 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     }
     auto coord = [&](int e) { return LDS_VERTS ? lv[e] : vb[e]; };
     const size_t nt = m.ntri;
+    // Without the lighting the image's triangles go to its blocks in equal shares (no short last block: 21.7 -> 20.0 us
+    // per 64 heads); with it full blocks and a short last one measured better (33.0 against 34.3 us).
+    const int tris_per_block = WITH_LIGHT ? kGeoTrisPerBlock : (m.ntri + (int)gridDim.x - 1) / (int)gridDim.x;
     uint2 box[kGeoPerThread];
 #pragma unroll
     for (int k = 0; k < kGeoPerThread; ++k) {
-        const int f = blockIdx.x * kGeoTrisPerBlock + k * kGeoThreads + tid;
+        const int fl = k * kGeoThreads + tid, f = blockIdx.x * tris_per_block + fl;
         box[k] = make_uint2(1u, 1u);  // empty
-        if (f >= m.ntri) continue;
+        if (fl >= tris_per_block || f >= m.ntri) continue;
         const int i0 = m.tri[3 * f], i1 = m.tri[3 * f + 1], i2 = m.tri[3 * f + 2];
         const float x0 = coord(3 * i0), y0 = coord(3 * i0 + 1), z0 = coord(3 * i0 + 2);
         const float x1 = coord(3 * i1), y1 = coord(3 * i1 + 1), z1 = coord(3 * i1 + 2);
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kGeoPerThread; ++k) {
-        const int f = blockIdx.x * kGeoTrisPerBlock + k * kGeoThreads + tid;
+        const int f = blockIdx.x * tris_per_block + k * kGeoThreads + tid;
         const int bx0 = box[k].x & 0xffff, bx1 = box[k].x >> 16, by0 = box[k].y & 0xffff, by1 = box[k].y >> 16;
         if (bx0 > bx1 || (DAD3D_K1_ABLATE & 3)) continue;  // empty box: in no list
         for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
