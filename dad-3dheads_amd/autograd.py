@@ -36,9 +36,10 @@ from .flame import MAX_EXPRESSION, MAX_SHAPE, FlameParams
 
 N_CONSTS = 72  # csrc/common.hpp kBackwardConsts
 # dL/d(v_posed) @ basis^T: the hand-written split-K kernel up to this batch, rocBLAS above. Measured on MI355X
-# (profiles/r02_bench_train.json): 23.7 vs 31.7 us at B = 64 (the reference's training batch, train_stage/flame_landmarks.yaml:10),
-# 34.0 vs 31.9 at 128, 54 vs 46 at 256, 178 vs 122 at 1024 -- every chunk of the 3V axis writes a [B, 512] partial, and that
-# traffic (15 MB per 64 images, written and read back) grows with the batch while the library's tiling does not pay it.
+# (profiles/r02_bench_train.json): 24.8 vs 31.6 us at B = 64 (the reference's training batch, train_stage/flame_landmarks.yaml:10),
+# 32.8 vs 31.8 at 128, 52 vs 45 at 256, 181 vs 120 at 1024: the library reaches ~0.73 of the fp32-MFMA peak on the large
+# shapes, this kernel ~0.5 (its multiplying waves share their SIMDs with the staging waves and re-read the image rows once per
+# output quarter); it wins where the launch is short enough for the library's fixed costs to show.
 GRAD_INPUTS_HIP_MAX_BATCH = 96
 
 

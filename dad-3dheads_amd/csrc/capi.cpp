@@ -64,8 +64,8 @@ struct dad3d_flame {
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
     float* d_bwd_partials = nullptr;  // [cap][kBackwardMaxSplit][72] scratch of dad3d_flame_decode_backward
     int bwd_cap = 0;
-    float* d_grad_partials = nullptr;  // [chunks][grad_cap][kGradRows] scratch of dad3d_flame_grad_inputs
-    int grad_cap = 0;                  // images, a multiple of kBlockImages
+    float* d_grad_partials = nullptr;  // [slices][padded batch][kGradRows] scratch of dad3d_flame_grad_inputs
+    size_t grad_cap = 0;               // its capacity in rows of kGradRows floats
     int n_lmk = 0;
     float* d_imgc = nullptr;
     unsigned* d_sync = nullptr;   // [0] arrival counter, [1] time-out counter; [4], [5], [last]: device-epoch launches
@@ -82,7 +82,9 @@ static int grad_chunks(const dad3d_flame* h) { return (h->n_verts * 3 + kGradChu
 // basis^T pack (once per model, shared by forks) and the split-K scratch for `batch` images (per handle)
 static dad3d_status grad_inputs_prepare(dad3d_flame* h, int batch, hipStream_t s) {
     const int pad = (batch + kBlockImages - 1) / kBlockImages * kBlockImages;
-    const bool need_pack = h->c->d_gpack == nullptr, need_scratch = pad > h->grad_cap;
+    const int per_slice = grad_chunks_per_slice(pad);
+    const size_t rows = (size_t)((grad_chunks(h) + per_slice - 1) / per_slice) * pad;
+    const bool need_pack = h->c->d_gpack == nullptr, need_scratch = rows > h->grad_cap;
     if (!need_pack && !need_scratch) return DAD3D_OK;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
@@ -111,8 +113,8 @@ static dad3d_status grad_inputs_prepare(dad3d_flame* h, int batch, hipStream_t s
         (void)hipFree(h->d_grad_partials);
         h->d_grad_partials = nullptr;
         h->grad_cap = 0;
-        DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_grad_partials), (size_t)grad_chunks(h) * pad * kGradRows * sizeof(float)));
-        h->grad_cap = pad;
+        DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_grad_partials), rows * kGradRows * sizeof(float)));
+        h->grad_cap = rows;
     }
     return DAD3D_OK;
 }
@@ -524,8 +526,9 @@ dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, in
     dad3d_status st = grad_inputs_prepare(h, batch, s);  // a no-op after the training forward of the same batch size
     if (st) return st;
     const int pad = (batch + kBlockImages - 1) / kBlockImages * kBlockImages;
+    const int per_slice = grad_chunks_per_slice(pad);
     GradInputsArgs ga{grad_posed, h->c->d_gpack, h->d_grad_partials, grad_inputs, batch, pad, h->n_verts * 3, grad_chunks(h),
-                      h->n_betas + 36};
+                      h->n_betas + 36, per_slice, (grad_chunks(h) + per_slice - 1) / per_slice};
     return launch_grad_inputs(ga, s);
 }
 

@@ -152,10 +152,12 @@ struct GradPackArgs {      // builds the MFMA B-fragment pack of basis^T from th
 struct GradInputsArgs {
     const float* g_posed;  // [B][n_cols]
     const float* gpack;
-    float* partials;       // [n_chunks][batch_pad][kGradRows]
+    float* partials;       // [n_slices][batch_pad][kGradRows]
     float* g_inputs;       // [B][n_inputs]
     int batch, batch_pad, n_cols, n_chunks, n_inputs;
+    int chunks_per_slice, n_slices;  // a workgroup multiplies `chunks_per_slice` consecutive chunks: partials [n_slices][batch_pad][kGradRows]
 };
+inline int grad_chunks_per_slice(int batch_pad) { return batch_pad / kBlockImages >= 4 ? 4 : batch_pad / kBlockImages >= 2 ? 2 : 1; }
 size_t grad_pack_floats(int n_chunks);
 dad3d_status launch_grad_pack(const GradPackArgs& a, hipStream_t s);
 dad3d_status launch_grad_inputs(const GradInputsArgs& a, hipStream_t s);

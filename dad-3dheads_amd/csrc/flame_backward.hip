@@ -418,13 +418,13 @@ dad3d_status launch_flame_backward(const BackwardArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 // The one contraction of the backward pass with the blend-shape basis (the transpose of the forward GEMM, flame.py:212-221
 // through torch autograd in the reference). The long axis is the contraction: the 3V columns are cut into chunks of 256 and a
-// workgroup owns (chunk, quarter of the outputs: 128 rows, 436 padded to 512). Its four waves take two 16-row tiles each and
-// keep their basis fragments -- all 16 column groups of the chunk, MFMA B-fragment order, built on the device from the
-// forward pack the first time a training forward runs -- in registers for the whole launch, while the workgroup walks the
-// batch in blocks of 64 images: the block's rows of dL/d(v_posed) are staged in LDS ([64][260] floats, ds_read_b128
-// conflict-free, two buffers: the next block is in flight while this one multiplies), 8 accumulator tiles of
-// v_mfma_f32_16x16x4_f32 per wave, stored straight to the chunk's partial [B][512]. A second small launch adds the chunks in
-// chunk order: no atomics, bit-reproducible.
+// workgroup owns (slice of 1-4 consecutive chunks, quarter of the outputs: 128 rows, 436 padded to 512, block of 64 images).
+// Four of its waves take two 16-row tiles each: basis fragments in MFMA B-fragment order (built on the device from the forward
+// pack the first time a training forward runs) stream through an eight-deep register ring, 8 accumulator tiles of
+// v_mfma_f32_16x16x4_f32 per wave live across the slice's chunks. The other four waves stage the image rows of the next chunk
+// in LDS ([64][260] floats, ds_read_b128 conflict-free, two buffers) while this one multiplies. The slice's partial [B][512]
+// goes to a scratch buffer and a second small launch adds the slices in order: no atomics, bit-reproducible. Slices grow with
+// the batch (1 chunk at B <= 64, 4 from B = 256 on: the image blocks fill the chip), so the partial traffic does not.
 namespace dad3d {
 namespace {
 
@@ -472,53 +472,64 @@ __global__ void grad_pack_kernel(GradPackArgs a) {
     reinterpret_cast<f32x4*>(a.gpack)[e] = out;
 }
 
+constexpr int kGradAhead = 8;  // basis fragments (column groups) in flight per multiplying wave: a ring of eight
+
+// One workgroup = (slice of the 3V axis: `chunks_per_slice` chunks of 256 columns, quarter of the outputs, block of 64
+// images). The accumulators live across the slice's chunks, so the partial sums a launch writes are [slices][B][512]:
+// the slices get longer as the batch grows (more image blocks fill the chip), the partial traffic does not.
 __global__ __launch_bounds__(kGradThreads) void grad_inputs_kernel(GradInputsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float a_lds[];  // [2][64][kGradLd]
-    const int chunk = blockIdx.x, nq = blockIdx.y;
+    const int slice = blockIdx.x, nq = blockIdx.y, img0 = blockIdx.z * kBlockImages;
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, tid = threadIdx.x & 255;
     const bool feeder = threadIdx.x >= 256;  // wave-uniform
-    const int c0 = chunk * kGradChunk;
+    const int chunk0 = slice * a.chunks_per_slice;
+    const int n_sub = min(a.chunks_per_slice, a.n_chunks - chunk0);
     const int row0 = nq * kGradQuarterRows + 32 * wave;  // this wave's 32 output rows
     const bool wave_live = !feeder && row0 < a.n_inputs;   // the padding of the last quarter is nobody's work
-    // this wave's basis fragments: resident for the whole launch
-    f32x4 bq[kGradGroups][2];
-    {
-        const f32x4* gp = reinterpret_cast<const f32x4*>(a.gpack) +
-                          ((((size_t)chunk * kGradQuarters + nq) * 4 + wave) * kGradGroups * 2) * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < kGradGroups; ++g)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) bq[g][tt] = wave_live ? gp[(size_t)(g * 2 + tt) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int col = c0 + tid;
-    const bool col_ok = col < a.n_cols;
-    const float* src = a.g_posed + min(col, a.n_cols - 1);
+
+    // feeders: rows of dL/d(v_posed) for one chunk -> LDS; rows past the batch and columns past 3V are zeros. All 64 loads
+    // of a thread are in flight together (clamped addresses, no branch per load).
     float stage[kBlockImages];
-    auto request = [&](int img0) {  // all 64 loads of a thread in flight together (clamped addresses, no branch per load)
+    auto request = [&](int chunk) {
+        const float* src = a.g_posed + min(chunk * kGradChunk + tid, a.n_cols - 1);
 #pragma unroll
         for (int r = 0; r < kBlockImages; ++r) stage[r] = src[(size_t)min(img0 + r, a.batch - 1) * a.n_cols];
     };
-    auto commit = [&](int img0, float* dst) {  // rows past the batch and columns past 3V are zeros
+    auto commit = [&](int chunk, float* dst) {
+        const bool col_ok = chunk * kGradChunk + tid < a.n_cols;
 #pragma unroll
         for (int r = 0; r < kBlockImages; ++r) dst[r * kGradLd + tid] = (col_ok && img0 + r < a.batch) ? stage[r] : 0.0f;
     };
+    // multiplying waves: the basis fragments of the slice are one linear sequence of (chunk, group) steps, read through a ring
+    const f32x4* gp = reinterpret_cast<const f32x4*>(a.gpack) + lane;
+    auto frag_ptr = [&](int step) {  // step = 16 * sub-chunk + group, clamped into the slice (a clamped load is never used)
+        const int st = min(step, n_sub * kGradGroups - 1);
+        const int chunk = chunk0 + st / kGradGroups, g = st % kGradGroups;
+        return gp + ((((size_t)chunk * kGradQuarters + nq) * 4 + wave) * kGradGroups + g) * 2 * 64;
+    };
+    f32x4 bq[kGradAhead][2];
+    f32x4 acc[4][2];
+    if (wave_live) {
+#pragma unroll
+        for (int k = 0; k < kGradAhead; ++k) {
+            const f32x4* fp = frag_ptr(k);
+            bq[k][0] = fp[0], bq[k][1] = fp[64];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (feeder) {
-        request(0);
-        commit(0, a_lds);
+        request(chunk0);
+        commit(chunk0, a_lds);
     }
     __syncthreads();
-    const int n_blocks = a.batch_pad / kBlockImages;
-    for (int mb = 0; mb < n_blocks; ++mb) {
-        const int img0 = mb * kBlockImages;
-        const float* cur = a_lds + (mb & 1) * kBlockImages * kGradLd;
-        if (feeder && mb + 1 < n_blocks) {  // the next block's rows, while the other four waves multiply this one
-            request(img0 + kBlockImages);
-            commit(img0 + kBlockImages, a_lds + ((mb + 1) & 1) * kBlockImages * kGradLd);
+    for (int sc = 0; sc < n_sub; ++sc) {
+        const float* cur = a_lds + (sc & 1) * kBlockImages * kGradLd;
+        if (feeder && sc + 1 < n_sub) {  // the next chunk's rows, while the other four waves multiply this one
+            request(chunk0 + sc + 1);
+            commit(chunk0 + sc + 1, a_lds + ((sc + 1) & 1) * kBlockImages * kGradLd);
         }
         if (wave_live) {
-            f32x4 acc[4][2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* afrag = cur + (lane & 15) * kGradLd + 4 * (lane >> 4);
             f32x4 af[4], an[4];
 #pragma unroll
@@ -535,20 +546,26 @@ __global__ __launch_bounds__(kGradThreads) void grad_inputs_kernel(GradInputsArg
                     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
-                            acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bq[g][tt][s], acc[m][tt], 0, 0, 0);
+                            acc[m][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bq[g % kGradAhead][tt][s], acc[m][tt], 0, 0, 0);
+                {   // the ring slot is free: the fragment eight steps ahead (possibly the next chunk's)
+                    const f32x4* fp = frag_ptr(sc * kGradGroups + g + kGradAhead);
+                    bq[g % kGradAhead][0] = fp[0], bq[g % kGradAhead][1] = fp[64];
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) af[m] = an[m];
             }
-            // D layout: row (image) = 16m + 4 (lane>>4) + reg, column (output) = 16 tt + (lane&15)
-            float* out = a.partials + ((size_t)chunk * a.batch_pad + img0) * kGradRows + row0 + (lane & 15);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) out[(size_t)(16 * m + 4 * (lane >> 4) + q) * kGradRows + 16 * tt] = acc[m][tt][q];
         }
         __syncthreads();
+    }
+    if (wave_live) {
+        // D layout: row (image) = 16m + 4 (lane>>4) + reg, column (output) = 16 tt + (lane&15)
+        float* out = a.partials + ((size_t)slice * a.batch_pad + img0) * kGradRows + row0 + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[(size_t)(16 * m + 4 * (lane >> 4) + q) * kGradRows + 16 * tt] = acc[m][tt][q];
     }
 }
 
@@ -559,14 +576,14 @@ __global__ void grad_inputs_reduce_kernel(GradInputsArgs a) {
     const float* src = a.partials + (size_t)b * kGradRows + r;
     const size_t step = (size_t)a.batch_pad * kGradRows;
     int c = 0;
-    for (; c + 16 <= a.n_chunks; c += 16) {  // sixteen loads in flight, added in chunk order
+    for (; c + 16 <= a.n_slices; c += 16) {  // sixteen loads in flight, added in slice order
         float v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(c + k) * step];
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += v[k];
     }
-    for (; c < a.n_chunks; ++c) s += src[(size_t)c * step];
+    for (; c < a.n_slices; ++c) s += src[(size_t)c * step];
     a.g_inputs[(size_t)b * a.n_inputs + r] = s;
 }
 
@@ -590,7 +607,7 @@ dad3d_status launch_grad_inputs(const GradInputsArgs& a, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done.set(dev);
     }
-    hipLaunchKernelGGL(grad_inputs_kernel, dim3(a.n_chunks, kGradQuarters), dim3(kGradThreads), lds, s, a);
+    hipLaunchKernelGGL(grad_inputs_kernel, dim3(a.n_slices, kGradQuarters, a.batch_pad / kBlockImages), dim3(kGradThreads), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(grad_inputs_reduce_kernel, dim3(a.batch), dim3(kGradRows), 0, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
