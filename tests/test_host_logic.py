@@ -289,3 +289,37 @@ def test_runtime_assets_are_package_data_not_test_fixtures():
     for path in (synthetic.static_fixture_path(), bx.embedding_path()):
         assert os.path.commonpath([pkg, os.path.abspath(path)]) == pkg and os.path.isfile(path), path
     assert os.path.isfile(os.path.join(pkg, "assets", "NOTICE.md"))  # licence of the bundled data
+
+
+def test_region_tables_for_the_fused_losses():
+    """losses.RegionTables (host logic of csrc/mesh_losses.hip): the region lists back to back, the same incidence
+    transposed per vertex in (vertex, region, position) order, negative indices like `tensor[:, i]`, and the per-vertex
+    weight the reprojection loss collapses into."""
+    import torch
+
+    from dad_3dheads_amd.losses import RegionTables
+
+    n = 50
+    idx = [np.array([3, 7, 7, 49]), np.array([-1, 0, 3]), np.zeros(0, dtype=np.int64), np.arange(10, 20)]
+    w = [1.0, 0.5, 9.0, 2.0]
+    t = RegionTables(w, idx, n, torch.device("cpu"))
+    assert t.n_regions == 4 and t.region_ptr.tolist() == [0, 4, 7, 7, 17]
+    assert t.region_idx.tolist()[:7] == [3, 7, 7, 49, 49, 0, 3]
+    ptr, reg, pos = t.vert_ptr.numpy(), t.vert_region.numpy(), t.vert_pos.numpy()
+    assert ptr[0] == 0 and ptr[-1] == 17 and (np.diff(ptr) >= 0).all()
+    flat, rptr = t.region_idx.numpy(), t.region_ptr.numpy()
+    seen = set()
+    for v in range(n):
+        entries = [(int(reg[e]), int(pos[e])) for e in range(ptr[v], ptr[v + 1])]
+        assert entries == sorted(entries)  # fixed summation order: by region, then position
+        for r, p in entries:
+            assert flat[rptr[r] + p] == v
+            seen.add((r, p))
+    assert len(seen) == 17  # every (region, position) exactly once
+    expect = np.zeros(n)
+    for wi, i in zip(w, idx):
+        for v in np.where(i < 0, i + n, i):
+            expect[v] += wi / max(len(i), 1)
+    assert np.allclose(t.point_weight.numpy(), expect, rtol=1e-6)
+    with pytest.raises(IndexError):
+        RegionTables([1.0], [np.array([50])], n, torch.device("cpu"))
