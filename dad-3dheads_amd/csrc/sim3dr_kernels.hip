@@ -415,30 +415,52 @@ __device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned*
         level = cost > kSplit2 ? 2 : cost > kSplit1 ? 1 : 0;
         bucket = min((int)((cost >> (2 * level)) >> 10), kQueueBuckets - 1);
     };
+    // This runs alone on the chip: every memory round trip is exposed. The first kQueueKeep lists of a thread (all of them
+    // for up to 2048 lists) are read ONCE, both counters in flight together, and kept in registers for the second pass.
+    constexpr int kQueueKeep = 2;
+    unsigned kept_c[kQueueKeep], kept_area[kQueueKeep];
+#pragma unroll
+    for (int k = 0; k < kQueueKeep; ++k) {
+        const int i = tid + k * kGeoThreads;
+        kept_c[k] = i < n_lists ? count_of(i) : 0u;
+        kept_area[k] = i < n_lists ? count_of(n_lists + i) : 0u;
+    }
+    auto counters = [&](int i, unsigned& c, unsigned& area) {
+        const int k = (i - tid) / kGeoThreads;
+        if (k < kQueueKeep) {
+            c = k == 0 ? kept_c[0] : kept_c[1], area = k == 0 ? kept_area[0] : kept_area[1];
+        } else {
+            c = count_of(i), area = count_of(n_lists + i);
+        }
+    };
     for (int i = tid; i < n_lists; i += kGeoThreads) {
-        const unsigned c = count_of(i);
+        unsigned c, area;
+        counters(i, c, area);
         if (!c) continue;
         int level, bucket;
-        plan(c, count_of(n_lists + i), level, bucket);
+        plan(c, area, level, bucket);
         atomicAdd(&hist[bucket], 1u << (2 * level));
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned run = 0;
-        for (int k = kQueueBuckets - 1; k >= 0; --k) {
-            const unsigned n = hist[k];
-            hist[k] = run;  // becomes the write cursor of the bucket
-            run += n;
+    if (tid < 64) {  // write cursors: exclusive suffix sums over the 64 buckets (heaviest first), one wave
+        static_assert(kQueueBuckets == 64, "one lane per bucket");
+        const unsigned n = hist[tid];
+        unsigned incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_down((int)incl, o, 64);
+            if (tid + o < 64) incl += up;
         }
-        sc.qhdr[0] = run;
-        sc.qhdr[1] = 0;
+        hist[tid] = incl - n;  // items in heavier buckets
+        if (tid == 0) sc.qhdr[0] = incl, sc.qhdr[1] = 0;
     }
     __syncthreads();
     for (int i = tid; i < n_lists; i += kGeoThreads) {
-        const unsigned c = count_of(i);
+        unsigned c, area;
+        counters(i, c, area);
         if (!c) continue;
         int level, bucket;
-        plan(c, count_of(n_lists + i), level, bucket);
+        plan(c, area, level, bucket);
         sc.counts[i] = 0, sc.counts[n_lists + i] = 0;  // leave the list empty for the next launch
         const unsigned parts = 1u << (2 * level);
         const unsigned pos = atomicAdd(&hist[bucket], parts);
