@@ -26,8 +26,9 @@ launches on ONE stream).
 
 Multi-GPU: images shard over ranks (weak scaling, 64 per GPU per step, no data-path collective); the timed
 region ends with the job's single RCCL all-gather of the last step's landmarks (north_star: "RCCL/xGMI
-only for the final gather"); with N > 1 `value` is the wall clock (the gather runs on RCCL's stream). Rank 0 prints ONE
-JSON line.
+only for the final gather"). Under a process group (any N) `value` comes from device events around [first launch ... end of
+the all-gather] on each rank, MAX over ranks: with the driver's 20 steps the wall clock would mostly measure the host's launch
+latency and the collective's host-side set-up, not the job. Rank 0 prints ONE JSON line.
 
 `--workload render` (BASELINE configs[4], not the headline metric): per step and GPU 64 images of head_mesh decode ->
 vertex normals + Phong light -> z-buffer raster of the 9976-triangle mesh onto 256 x 256 x 3 (three launches), the timed
@@ -313,9 +314,11 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
 
     handle, stream = sets[0]["call"][0], sets[0]["call"][-1]
     tot, cnt = C.c_double(), C.c_int()
+    region0, region1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence(dist, dev)
     t0 = time.perf_counter()
     if n_streams == 1:  # two hipEvents on the launch stream bracket the K launches of the timed region itself
+        region0.record(streams[0])
         _lib.check(lib.dad3d_flame_profile_begin(handle, stream))
     for k in range(args.steps):
         step(k)
@@ -323,8 +326,11 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     if dist is not None:
         gather_last(args.steps - 1)
+        region1.record(torch.cuda.current_stream(dev))  # behind the collective: the region's device time, host latency aside
     fence(dist, dev)
     wall = max_over_ranks(dist, dev, time.perf_counter() - t0)
+    # Under a process group the job's device time is [first launch .. end of the all-gather] on this rank, MAX over ranks
+    region_s = max_over_ranks(dist, dev, region0.elapsed_time(region1) * 1e-3) if (dist is not None and n_streams == 1) else None
 
     # dominant-kernel duration = hipEvent time of the K back-to-back launches / K (one kernel per step). With one
     # stream the events bracketed the timed region; with several, kernels of different streams overlap and a launch's
@@ -351,8 +357,10 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
     images = world * BATCH * args.steps
     flops = FLOP_PER_IMAGE * BATCH
     alg_bytes = CONST_BYTES + BATCH * BYTES_PER_IMAGE
-    from_events = n_streams == 1 and world == 1  # one stream, no collective inside the region: the events ARE the K steps
-    elapsed = events_s if from_events else wall
+    # one stream: device events ARE the timed region (K launches; plus the final all-gather under a process group); the wall
+    # clock of a short region (the driver's 20 steps) mostly measures the host's launch latency
+    from_events = n_streams == 1
+    elapsed = (region_s if region_s is not None else events_s) if from_events else wall
     traffic, traffic_src = pmc_json("pmc_traffic", "traffic_bytes_per_launch")
     mfma_busy, mfma_src = pmc_json("pmc_sq", "mfma_busy_fraction_of_kernel_time_all_1024_simds")
     out = {
@@ -381,7 +389,8 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                               if dist is not None else " (no process group: plain N=1 run)"),
             "streams": n_streams,
             "prewarm_ms": prewarm_ms,
-            "value_from": "hipEvents on the launch stream around the K timed launches (MAX over ranks)" if from_events
+            "value_from": ("device events around the K timed launches AND the final all-gather (MAX over ranks)" if region_s is not None
+                           else "hipEvents on the launch stream around the K timed launches") if from_events
                           else "wall clock between barrier+synchronize pairs (MAX over ranks)",
             "images_per_sec_wall": images / wall,
             "single_stream_ms_per_step": kern_s * 1e3,
@@ -436,25 +445,27 @@ def run_render(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         step(k)
     if dist is not None:
         gather_last()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e_steps, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     fence(dist, dev)
     t0 = time.perf_counter()
     e0.record()
     for k in range(args.steps):
         step(k)
-    e1.record()
-    if dist is not None:
+    e_steps.record()
+    if dist is not None:  # under a process group the region ends behind the all-gather (same stream as the steps)
         gather_last()
+    e1.record()
     fence(dist, dev)
     wall = max_over_ranks(dist, dev, time.perf_counter() - t0)
     ev_s = max_over_ranks(dist, dev, e0.elapsed_time(e1) * 1e-3)
+    steps_s = e0.elapsed_time(e_steps) * 1e-3  # this rank's K steps alone: the per-step duration behind `roofline`
     if rank != 0:
         return None
     img = renderer._img
     covered = float((img.reshape(BATCH, -1).max(dim=1).values > 0).float().mean().item())
     ok_gather = True if dist is None else bool(torch.equal(gathered[:BATCH], img))
     images = world * BATCH * args.steps
-    elapsed = ev_s if world == 1 else wall
+    elapsed = ev_s  # device events: the K steps (plus the final all-gather under a process group), MAX over ranks
     alg = BATCH * (RASTER_BYTES_PER_IMAGE + 120_552) + CONST_BYTES + BATCH * (1652 + 60_276)
     out = {
         "metric": "images/sec (head_mesh decode + Sim3DR face-mesh render), batch 64 @ 256^2 per GPU",
@@ -467,10 +478,10 @@ def run_render(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                    "batch_per_gpu": BATCH, "global_batch": world * BATCH,
                    "parallelism": f"image-sharded x{world}, one final RCCL all-gather of [64,256,256,3] uint8 per rank",
                    "prewarm_ms": prewarm_ms, "images_with_coverage": covered, "gather_verified": ok_gather,
-                   "value_from": "torch events around the K timed steps" if world == 1 else "wall clock (MAX over ranks)"},
+                   "value_from": "device events around the K timed steps" + (" AND the final all-gather (MAX over ranks)" if dist is not None else "")},
         "roofline": {"kernel": "decode + tri_geometry(+normals+light) + raster_kernel, three launches", "bound": "hbm",
-                     "achieved": alg / (ev_s / args.steps) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": alg / (ev_s / args.steps) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                     "achieved": alg / (steps_s / args.steps) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": alg / (steps_s / args.steps) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                      "algorithmic_bytes_per_step": alg},
     }
     if world == 1 and not args.no_cpu_baseline:
