@@ -372,7 +372,10 @@ constexpr int kGeoThreads = kStageThreads;
 constexpr int kGeoPerThread = 3;
 constexpr int kGeoTrisPerBlock = kGeoThreads * kGeoPerThread;
 constexpr int kMaxTiles = 4096;      // LDS counters of the geometry kernel
-constexpr unsigned kSplit1 = 40000, kSplit2 = 160000;  // tile cost (pixel tests + 8 per triangle) above which a tile
+#ifndef DAD3D_SPLIT1  // swept at the end of round 2 (64 heads, 256 x 256): 20 k 57.9 us, 30 k 52.1, 40 k 47.8, 48 k 46.0, 55 k 43.0,
+#define DAD3D_SPLIT1 56000u  // 60 k 43.4, 80 k 43.4, 150 k 43.9, never 43.7 -- every part re-reads its tile's whole list
+#endif
+constexpr unsigned kSplit1 = DAD3D_SPLIT1, kSplit2 = 4 * DAD3D_SPLIT1;  // tile cost (pixel tests + 8 per triangle) above which a tile
                                                         // is split 2x2 / 4x4
 constexpr int kMaxSubs = 16;
 constexpr int kQueueBuckets = 64;
