@@ -377,6 +377,10 @@ constexpr int kMaxTiles = 4096;      // LDS counters of the geometry kernel
 #endif
 constexpr unsigned kSplit1 = DAD3D_SPLIT1, kSplit2 = 4 * DAD3D_SPLIT1;  // tile cost (pixel tests + 8 per triangle) above which a tile
                                                         // is split 2x2 / 4x4
+#ifndef DAD3D_LANE_SHIFT  // swept (raster_kernel, 64 heads): 1 -> 49.6 us, 2 -> 42.9, 3 -> 45.0, 4 -> 48.1
+#define DAD3D_LANE_SHIFT 2
+#endif
+constexpr int kLaneShift = DAD3D_LANE_SHIFT;  // a class-c triangle (box area <= 2^(c+1)) gets 2^max(c - kLaneShift, 0) lanes: <= 2^(kLaneShift+1) tests per lane
 constexpr int kMaxSubs = 16;
 constexpr int kQueueBuckets = 64;
 constexpr unsigned kNoTri = 0xFFFFFFFFu;
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             int before = 0, sb = 0, all = 0, sall = 0;
 #pragma unroll
             for (int cc = 0; cc < kClasses; ++cc) {
-                const int n_cc = cnum[cc], s_cc = ((n_cc << max(cc - 2, 0)) + 63) & ~63;
+                const int n_cc = cnum[cc], s_cc = ((n_cc << max(cc - kLaneShift, 0)) + 63) & ~63;
                 if (cc < pc) before += n_cc, sb += s_cc;
                 all += n_cc, sall += s_cc;
             }
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a)
             sl.valid = false;
             if (s0 >= n_slots) return;
             const int c = __builtin_popcountll(__ballot(s0 >= class_start));
-            sl.lg = max(c - 2, 0);
+            sl.lg = max(c - kLaneShift, 0);
             const int local = s0 + lane - sbase[c];
             const int ti = local >> sl.lg;
             sl.sub = local & ((1 << sl.lg) - 1);
