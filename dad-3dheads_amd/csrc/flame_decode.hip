@@ -456,7 +456,7 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
 // Decode-role workgroup = 8 waves. Waves 0-3 ("mma", one per SIMD) request their whole basis slice (26 x 1 KiB
 // per wave, fragment-ordered by the host) into VGPRs up front and then do nothing but ds_read + MFMA. Waves 4-7
 // ("feeders", one per SIMD beside an mma wave) copy the 64 params rows into the row-major A image in four
-// parts of growing size (6, 8 and the remaining MFMA groups), write the pose-feature rows, and fetch the
+// parts (8, 8 and the remaining MFMA groups), write the pose-feature rows, and fetch the
 // pose role's block -- so global-load latency, vmcnt waits and ds_write issue never sit in an MFMA wave's
 // instruction stream, the GEMM starts after 3/13 of A has landed, and only three workgroup barriers (one per
 // part, each placed one group before the part's first use so the fragment prefetch can cross it) interrupt it.
@@ -464,9 +464,13 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
 // CONTIG: params[:, 0:400] are the betas (shape == 300, expression == 100: the dad_3dnet.yaml constants), so
 // the A operand is copied with 16-byte loads; otherwise it is gathered element by element (flame.py:192-200).
 template <int KG>
-struct Parts {  // A-image parts in MFMA groups of 16 k: [0,6) [6,14) [14,KG)
+struct Parts {  // A-image parts in MFMA groups of 16 k: [0,8) [8,16) [16,KG)
     static constexpr int n = 3;
-    static constexpr int begin(int p) { return p == 0 ? 0 : p == 1 ? 6 : p == 2 ? 14 : KG; }
+#ifndef DAD3D_PART1  // swept at the end of round 2 (us at B = 64 / 128 / 256 / 1024): {4,12} 13.8 / 25.2 / 47.2 / 168, {6,14} (rounds
+#define DAD3D_PART1 8   // 1-2) 13.1 / 23.7 / 45.1 / 172, {8,16} 12.9 / 23.0 / 44.0 / 167, {10,16} 12.8 / 23.0 / 44.0 / 167,
+#define DAD3D_PART2 16  // {10,18} 13.1 / 23.3 / 44.4 / 174, {12,20} 13.0 / 23.4 / 44.3 / 172, {8,20} 12.9 / 23.3 / 43.9 / 172
+#endif
+    static constexpr int begin(int p) { return p == 0 ? 0 : p == 1 ? DAD3D_PART1 : p == 2 ? DAD3D_PART2 : KG; }
 };
 
 // RB = 16-image MFMA row blocks per workgroup: 4, or 1 for launches of at most 16 images (a single image is how the
