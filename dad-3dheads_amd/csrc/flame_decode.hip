@@ -458,7 +458,7 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
 // ("feeders", one per SIMD beside an mma wave) copy the 64 params rows into the row-major A image in four
 // parts (8, 8 and the remaining MFMA groups), write the pose-feature rows, and fetch the
 // pose role's block -- so global-load latency, vmcnt waits and ds_write issue never sit in an MFMA wave's
-// instruction stream, the GEMM starts after 3/13 of A has landed, and only three workgroup barriers (one per
+// instruction stream, the GEMM starts after 4/13 of A has landed, and only three workgroup barriers (one per
 // part, each placed one group before the part's first use so the fragment prefetch can cross it) interrupt it.
 //
 // CONTIG: params[:, 0:400] are the betas (shape == 300, expression == 100: the dad_3dnet.yaml constants), so
