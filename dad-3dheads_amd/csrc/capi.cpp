@@ -608,6 +608,10 @@ struct dad3d_mesh {
     int ntri = 0, nver = 0;
     int *d_tri = nullptr, *d_adj_ptr = nullptr, *d_adj_face = nullptr;
     int4* d_adj_tri = nullptr;
+    int4* d_nc_faces[kNormalChunkings] = {};  // chunk face lists of the normals kernels (NormalChunksDev)
+    int* d_nc_ptr[kNormalChunkings] = {};
+    int* d_nc_slot[kNormalChunkings] = {};
+    NormalChunksDev nc[kNormalChunkings] = {};
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_mesh_debug_trace)
     void* d_raster = nullptr;  // per-image triangle boxes + corner planes, grown on demand (one stream at a time)
     size_t raster_bytes = 0;
@@ -665,6 +669,47 @@ dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int devic
         dad3d_mesh_destroy(m.release());
         return st;
     }
+    // chunk face lists for 1, 2, 4 and 8 vertex chunks per image (only where table + staged vertices fit the LDS)
+    for (int k = 0; k < kNormalChunkings && nver > 0 && ntri > 0; ++k) {
+        const int chunks = 1 << k, vpb = (nver + chunks - 1) / chunks;
+        std::vector<int> fptr(chunks + 1, 0), slot(face.size(), 0);
+        std::vector<std::vector<int4>> lists(chunks);
+        std::vector<int> pos_of(3 * (size_t)ntri);  // (face, corner) -> position of the face in the list of the corner's chunk
+        for (int f = 0; f < ntri; ++f) {
+            int seen_chunk[3], seen_pos[3], n_seen = 0;
+            for (int c = 0; c < 3; ++c) {
+                const int ch = tri[3 * f + c] / vpb;
+                int p = -1;
+                for (int j = 0; j < n_seen; ++j)
+                    if (seen_chunk[j] == ch) p = seen_pos[j];
+                if (p < 0) {
+                    p = (int)lists[ch].size();
+                    lists[ch].push_back(make_int4(tri[3 * f], tri[3 * f + 1], tri[3 * f + 2], f));
+                    seen_chunk[n_seen] = ch, seen_pos[n_seen] = p, ++n_seen;
+                }
+                pos_of[3 * (size_t)f + c] = p;
+            }
+        }
+        {   // slot[e] for the CSR entries, filled in the same (face-ascending) order as `face`
+            std::vector<int> cursor(ptr.begin(), ptr.end() - 1);
+            for (int f = 0; f < ntri; ++f)
+                for (int c = 0; c < 3; ++c) slot[cursor[tri[3 * f + c]]++] = pos_of[3 * (size_t)f + c];
+        }
+        int max_faces = 0;
+        std::vector<int4> flat;
+        for (int ch = 0; ch < chunks; ++ch) {
+            fptr[ch] = (int)flat.size();
+            flat.insert(flat.end(), lists[ch].begin(), lists[ch].end());
+            max_faces = std::max(max_faces, (int)lists[ch].size());
+        }
+        fptr[chunks] = (int)flat.size();
+        if (normal_table_lds_bytes(nver, max_faces) > 160 * 1024 - 1024) continue;
+        if ((st = upload(&m->d_nc_faces[k], flat)) || (st = upload(&m->d_nc_ptr[k], fptr)) || (st = upload(&m->d_nc_slot[k], slot))) {
+            dad3d_mesh_destroy(m.release());
+            return st;
+        }
+        m->nc[k] = NormalChunksDev{m->d_nc_faces[k], m->d_nc_ptr[k], m->d_nc_slot[k], chunks, vpb, max_faces};
+    }
     *out = m.release();
     return DAD3D_OK;
 }
@@ -674,6 +719,9 @@ void dad3d_mesh_destroy(dad3d_mesh* m) {
     DeviceGuard guard(m->device);
     for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_adj_tri, m->d_raster})
         if (p) (void)hipFree(p);
+    for (int k = 0; k < kNormalChunkings; ++k)
+        for (void* p : {(void*)m->d_nc_faces[k], (void*)m->d_nc_ptr[k], (void*)m->d_nc_slot[k]})
+            if (p) (void)hipFree(p);
     delete m;
 }
 
@@ -683,7 +731,7 @@ dad3d_status dad3d_mesh_get_normal(dad3d_mesh* m, float* ver_normal, const float
     if (batch == 0 || m->nver == 0) return DAD3D_OK;
     DAD3D_REQUIRE(ver_normal && vertices, "dad3d_mesh_get_normal: null buffer");
     DeviceGuard guard(m->device);
-    return launch_get_normal(m->dev(), ver_normal, vertices, batch, flags, static_cast<hipStream_t>(stream));
+    return launch_get_normal(m->dev(), m->nc, ver_normal, vertices, batch, flags, static_cast<hipStream_t>(stream));
 }
 
 dad3d_status dad3d_mesh_get_tri_normal(dad3d_mesh* m, float* tri_normal, const float* vertices, int batch,

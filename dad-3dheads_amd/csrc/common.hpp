@@ -192,12 +192,26 @@ struct MeshDev {
     int ntri, nver;
 };
 
+// Face lists of vertex chunks (normals, round 3): the vertices are cut into `chunks` ranges of `vpb`; chunk c lists every
+// face with a corner in its range (ascending face index). A workgroup computes each of those face normals ONCE into an
+// LDS table, then a vertex sums its table entries in ascending face order -- the serial scatter-add order of
+// rasterize_kernel.cpp:188-198 -- instead of recomputing every incident face from its corners.
+constexpr int kNormalChunkings = 4;  // 1, 2, 4, 8 chunks per image
+struct NormalChunksDev {
+    const int4* faces;    // [face_ptr[chunks]]  (i0, i1, i2, face), chunk after chunk
+    const int* face_ptr;  // [chunks + 1]
+    const int* slot;      // [3*ntri]  aligned with adj_face: position of adj_face[e] in the list of its vertex's chunk
+    int chunks, vpb, max_faces;  // chunks == 0: not built (mesh too large for the LDS table)
+};
+
 dad3d_status launch_tri_normal(const MeshDev& m, float* tri_normal, const float* vertices, int batch, int norm_flg,
                                hipStream_t s);
 dad3d_status launch_ver_normal(const MeshDev& m, float* ver_normal, const float* tri_normal, int batch,
                                unsigned flags, hipStream_t s);
-dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float* vertices, int batch, unsigned flags,
-                               hipStream_t s);
+dad3d_status launch_get_normal(const MeshDev& m, const NormalChunksDev* nc, float* ver_normal, const float* vertices,
+                               int batch, unsigned flags, hipStream_t s);
+// bytes of LDS the face-normal-table kernels need for a chunking with `max_faces` faces in its largest chunk
+size_t normal_table_lds_bytes(int nver, int max_faces);
 // scratch: raster_scratch_bytes(..) bytes of device memory (per-image triangle boxes, setup planes, per-tile
 // triangle lists), zeroed once with raster_scratch_init before its first use
 size_t raster_scratch_bytes(const MeshDev& m, int batch, int h, int w);

@@ -216,6 +216,85 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m
     }
 }
 
+// _get_normal through a face-normal table (round 3): block = (vertex chunk, image). Every face with a corner in the chunk is
+// crossed ONCE (one lane per face, nine LDS reads) into a float4 table in LDS; a vertex then adds its table entries in
+// ascending face order: one ds_read_b128 per incident face instead of nine scattered ds_read_b32 and a cross product.
+// 1.3 x ntri cross products per image at four chunks instead of 3 x ntri, ~24 instead of ~54 LDS reads per vertex.
+// Identical expressions and summation order => identical bits.
+constexpr int kFacesAhead = 4;  // chunk faces of a thread requested before the staging (FLAME, 4 chunks: 3.6 per thread)
+struct SlotRow {
+    int e0, e1;
+    int s[kAdjAhead];
+};
+__device__ __forceinline__ SlotRow load_slot_row(const MeshDev& m, const NormalChunksDev& nc, int v, bool live) {
+    SlotRow r;
+    r.e0 = live ? m.adj_ptr[v] : 0;
+    r.e1 = live ? m.adj_ptr[v + 1] : 0;
+#pragma unroll
+    for (int j = 0; j < kAdjAhead; ++j) r.s[j] = (r.e0 + j < r.e1) ? nc.slot[r.e0 + j] : 0;
+    return r;
+}
+__device__ __forceinline__ int normal_table_offset(int nver) { return (nver * 3 + 8 + 3) & ~3; }  // floats in front of the table
+
+// Phase A: the chunk's face normals into fn[] (caller: barrier afterwards). cf = the thread's first kFacesAhead faces.
+__device__ __forceinline__ void fill_face_table(const NormalChunksDev& nc, const float* lv, float4* fn, int f0, int nf,
+                                                const int4 (&cf)[kFacesAhead], int tid) {
+    auto put = [&](int i, const int4& f) {
+        float n[3];
+        face_cross(lv, f.x, f.y, f.z, n);
+        fn[i] = make_float4(n[0], n[1], n[2], 0.0f);
+    };
+#pragma unroll
+    for (int j = 0; j < kFacesAhead; ++j)
+        if (tid + j * kStageThreads < nf) put(tid + j * kStageThreads, cf[j]);
+    for (int i = tid + kFacesAhead * kStageThreads; i < nf; i += kStageThreads) put(i, nc.faces[f0 + i]);
+}
+// Phase B for one vertex: acc += its incident face normals, ascending face order
+__device__ __forceinline__ void add_table_faces(const NormalChunksDev& nc, const float4* fn, const SlotRow& r, float acc[3]) {
+    auto add = [&](int s) {
+        const float4 n = fn[s];
+        acc[0] += n.x;
+        acc[1] += n.y;
+        acc[2] += n.z;
+    };
+#pragma unroll
+    for (int j = 0; j < kAdjAhead; ++j)
+        if (r.e0 + j < r.e1) add(r.s[j]);
+    for (int e = r.e0 + kAdjAhead; e < r.e1; ++e) add(nc.slot[e]);
+}
+
+__global__ __launch_bounds__(kStageThreads) void ver_normal_table_kernel(MeshDev m, NormalChunksDev nc, float* ver_normal,
+                                                                         const float* vertices, unsigned flags) {
+    extern __shared__ __attribute__((aligned(16))) float lds_t[];
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const int f0 = nc.face_ptr[blockIdx.x], nf = nc.face_ptr[blockIdx.x + 1] - f0;
+    int4 cf[kFacesAhead];
+#pragma unroll
+    for (int j = 0; j < kFacesAhead; ++j)
+        cf[j] = (tid + j * kStageThreads < nf) ? nc.faces[f0 + tid + j * kStageThreads] : make_int4(0, 0, 0, 0);
+    const int v_end = min(m.nver, ((int)blockIdx.x + 1) * nc.vpb);
+    const int v0 = blockIdx.x * nc.vpb + tid;
+    SlotRow row = load_slot_row(m, nc, v0, v0 < v_end);  // in flight while the vertices are staged
+    const float* lv = stage_floats(lds_t, vertices + b * m.nver * 3, m.nver * 3, tid);
+    float4* fn = reinterpret_cast<float4*>(lds_t + normal_table_offset(m.nver));
+    __syncthreads();
+    fill_face_table(nc, lv, fn, f0, nf, cf, tid);
+    __syncthreads();
+    for (int v = v0; v < v_end; v += kStageThreads) {
+        const SlotRow cur = row;
+        row = load_slot_row(m, nc, v + kStageThreads, v + kStageThreads < v_end);
+        float* d = ver_normal + (b * m.nver + v) * 3;
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+        if (flags & DAD3D_NORMAL_ACCUMULATE) acc[0] = d[0], acc[1] = d[1], acc[2] = d[2];
+        add_table_faces(nc, fn, cur, acc);
+        unit3(acc);
+        d[0] = acc[0];
+        d[1] = acc[1];
+        d[2] = acc[2];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Phong vertex lighting (Sim3DR/lighting.py:37-62)
 // ------------------------------------------------------------------------------------------------
@@ -356,11 +435,20 @@ __global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* 
 //                        once from the record of its winning triangle and merged into the image as whole dwords.
 // The z-buffer never touches HBM; list and queue order are irrelevant to the result because the key maximum is
 // order-independent.
-constexpr int kTile = 64;            // screen tile edge; 64*64 u64 keys = 32 KiB
-constexpr int kTileShift = 6;
-constexpr int kRasterThreads = 512;
+#ifndef DAD3D_TILE_SHIFT
+#define DAD3D_TILE_SHIFT 6
+#endif
+#ifndef DAD3D_RASTER_THREADS
+#define DAD3D_RASTER_THREADS 512
+#endif
+#ifndef DAD3D_RASTER_WAVES_PER_SIMD
+#define DAD3D_RASTER_WAVES_PER_SIMD 4
+#endif
+constexpr int kTileShift = DAD3D_TILE_SHIFT;
+constexpr int kTile = 1 << kTileShift;  // screen tile edge; 64*64 u64 keys = 32 KiB
+constexpr int kRasterThreads = DAD3D_RASTER_THREADS;
 constexpr int kRasterWaves = kRasterThreads / 64;
-constexpr int kListCap = 4096;       // list entries sorted per round (u32 ids, 16 KiB)
+constexpr int kListCap = 8 * kRasterThreads;  // list entries sorted per round (u32 ids, 16 KiB)
 constexpr int kListPerThread = kListCap / kRasterThreads;
 constexpr int kClasses = 12;         // box area <=2, <=4, <=8, <=16, ... <=4096 (= a whole tile)
 constexpr int kSpread = 16;          // copies of every class counter: 64 lanes hit 16 addresses instead of one
@@ -475,6 +563,9 @@ __device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned*
     }
 }
 
+#ifndef DAD3D_NORMALS_OLD  // diagnostics: 1 = the per-vertex cross-product kernel of rounds 1-2
+#define DAD3D_NORMALS_OLD 0
+#endif
 #ifndef DAD3D_RK_ABLATE  // diagnostics only: 1 no fragment walk, 2 no resolve, 4 resolve without colour gathers, 8 without records
 #define DAD3D_RK_ABLATE 0
 #endif
@@ -636,7 +727,7 @@ __device__ __forceinline__ unsigned depth_order_number(float z) {
 // launch bounds: 4 waves per SIMD = two workgroups per CU (<= 128 VGPRs), so one item's latency-bound phases (sort,
 // resolve) overlap the other's ALU-bound fragment walk
 template <int MODE>
-__global__ __launch_bounds__(kRasterThreads, 4) void raster_kernel(RasterArgs a) {
+__global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void raster_kernel(RasterArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[kTile * kTile];
     __shared__ unsigned slist[kListCap];          // triangle ids of this round, sorted by class
     __shared__ int ccount[kClasses][kSpread];     // triangles per (class, counter copy); then write cursors
@@ -1113,11 +1204,37 @@ dad3d_status launch_ver_normal(const MeshDev& m, float* ver_normal, const float*
     return DAD3D_OK;
 }
 
-dad3d_status launch_get_normal(const MeshDev& m, float* ver_normal, const float* vertices, int batch, unsigned flags,
-                               hipStream_t s) {
+size_t normal_table_lds_bytes(int nver, int max_faces) {
+    return ((size_t)((nver * 3 + 8 + 3) & ~3) + 4 * (size_t)max_faces) * sizeof(float);
+}
+
+// the chunking to use for `batch` images: the coarsest one that still puts a block on every CU, among those that were built
+static const NormalChunksDev* pick_normal_chunks(const NormalChunksDev* nc, int nver, int batch) {
+    if (!nc) return nullptr;
+    const int want = (nver + staged_verts_per_block(nver, batch) - 1) / staged_verts_per_block(nver, batch);
+    for (int k = 0; k < kNormalChunkings; ++k)
+        if (nc[k].chunks >= want) return &nc[k];
+    for (int k = kNormalChunkings - 1; k >= 0; --k)
+        if (nc[k].chunks) return &nc[k];
+    return nullptr;
+}
+
+dad3d_status launch_get_normal(const MeshDev& m, const NormalChunksDev* nc_all, float* ver_normal, const float* vertices,
+                               int batch, unsigned flags, hipStream_t s) {
     if (m.nver == 0 || batch == 0) return DAD3D_OK;
     const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
-    if (lds <= kMaxDynamicLds) {
+    const NormalChunksDev* nc = pick_normal_chunks(nc_all, m.nver, batch);
+    if (nc && !(DAD3D_NORMALS_OLD)) {
+        static PerDeviceOnce attr_done;
+        const int dev = PerDeviceOnce::current();
+        if (!attr_done.done(dev)) {
+            DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ver_normal_table_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
+            attr_done.set(dev);
+        }
+        hipLaunchKernelGGL(ver_normal_table_kernel, dim3(nc->chunks, batch), dim3(kStageThreads),
+                           normal_table_lds_bytes(m.nver, nc->max_faces), s, m, *nc, ver_normal, vertices, flags);
+    } else if (lds <= kMaxDynamicLds) {
         static PerDeviceOnce attr_done;
         const int dev = PerDeviceOnce::current();
         if (!attr_done.done(dev)) {

@@ -34,8 +34,16 @@ def available(kind: str) -> bool:
     return os.path.isfile(os.path.join(_REF_DIR, f"libsim3dr_{'ref' if kind == 'reference' else 'port'}.so"))
 
 
+def best_kind() -> str:
+    """"reference" when the reference's own compiled C++ is there (it is built in the authoring container and ships to
+    the GPU box inside oracle/_ref/), else the C port that is pinned to it bit for bit (tests/test_oracle_sim3dr.py)."""
+    return "reference" if available("reference") else "port"
+
+
 class Sim3DROracle:
     def __init__(self, kind: str = "port"):
+        if kind == "best":
+            kind = best_kind()
         assert kind in ("port", "reference")
         self.kind = kind
         name = "libsim3dr_ref.so" if kind == "reference" else "libsim3dr_port.so"

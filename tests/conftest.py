@@ -68,3 +68,12 @@ def port_oracle():
     from oracle.sim3dr_ref import Sim3DROracle
 
     return Sim3DROracle("port")
+
+
+@pytest.fixture(scope="session")
+def sim3dr_oracle():
+    """The checker of the GPU tests: the reference's own rasterize_kernel.cpp (oracle/_ref/libsim3dr_ref.so, compiled in the
+    authoring container, shipped to the GPU box) whenever it is present, the C port otherwise."""
+    from oracle.sim3dr_ref import Sim3DROracle
+
+    return Sim3DROracle("best")

@@ -26,7 +26,7 @@ def test_render_batch_matches_oracle(estimator, flame_consts):
     assert params[:, 411].abs().max() == 0  # reprojected_vertices' side effect (head_mesh.py:41)
     verts = estimator.head_mesh.flame.decode(params, proj=True, to_2d=False, flip_z=True)["proj"]
     assert (verts.cpu() - ref_v).abs().max() < 1e-3  # pixel units
-    oracle = sim3dr_ref.Sim3DROracle()
+    oracle = sim3dr_ref.Sim3DROracle("best")
     faces = estimator.faces_wo_back_remapped.astype(np.int32)
     colors = estimator.colors.astype(np.float32)
     for i in range(b):  # the raster itself is bit-exact on identical vertices

@@ -67,7 +67,7 @@ def test_sharded_landmark_decoder_under_rccl_matches_oracle(nccl_world1, head_me
     assert torch.equal(dec(params), got)
 
 
-def test_sharded_renderer_under_rccl_matches_oracle(nccl_world1, head_mesh, flame_consts, static, port_oracle):
+def test_sharded_renderer_under_rccl_matches_oracle(nccl_world1, head_mesh, flame_consts, static, sim3dr_oracle):
     """BASELINE config 5's per-rank code path: decode -> normals + Phong + raster -> all-gather of uint8 images."""
     from dad_3dheads_amd import sharding, synthetic
     from dad_3dheads_amd.Sim3DR import Mesh
@@ -87,8 +87,8 @@ def test_sharded_renderer_under_rccl_matches_oracle(nccl_world1, head_mesh, flam
         # the oracle renders the GPU's own decoded vertices (decode parity has its own tests; this one is about the chain)
         v_gpu = np.ascontiguousarray(renderer._dec["proj"][i].cpu().numpy())
         assert np.abs(v_gpu - verts[i]).max() < 1e-3
-        ref, ref_light = sim3dr_ref.render_pipeline_ref(port_oracle, v_gpu.copy(), faces, np.zeros((256, 256, 3), np.uint8))
-        assert_render_bytes_explained(imgs[i].cpu().numpy(), ref, port_oracle, v_gpu, faces, ref_light)
+        ref, ref_light = sim3dr_ref.render_pipeline_ref(sim3dr_oracle, v_gpu.copy(), faces, np.zeros((256, 256, 3), np.uint8))
+        assert_render_bytes_explained(imgs[i].cpu().numpy(), ref, sim3dr_oracle, v_gpu, faces, ref_light)
     again = renderer(params.cuda())  # buffers are reused: same bytes
     assert torch.equal(again, imgs)
 
