@@ -608,9 +608,9 @@ struct dad3d_mesh {
     int ntri = 0, nver = 0;
     int *d_tri = nullptr, *d_adj_ptr = nullptr, *d_adj_face = nullptr;
     int4* d_adj_tri = nullptr;
-    int4* d_nc_faces[kNormalChunkings] = {};  // chunk face lists of the normals kernels (NormalChunksDev)
-    int* d_nc_ptr[kNormalChunkings] = {};
-    int* d_nc_slot[kNormalChunkings] = {};
+    uint2* d_nc_faces[kNormalChunkings] = {};  // chunk face lists of the normals kernels (NormalChunksDev)
+    unsigned short* d_nc_slot[kNormalChunkings] = {};
+    uint4* d_nc_row8[kNormalChunkings] = {};
     NormalChunksDev nc[kNormalChunkings] = {};
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_mesh_debug_trace)
     void* d_raster = nullptr;  // per-image triangle boxes + corner planes, grown on demand (one stream at a time)
@@ -670,7 +670,7 @@ dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int devic
         return st;
     }
     // chunk face lists for 1, 2, 4 and 8 vertex chunks per image (only where table + staged vertices fit the LDS)
-    for (int k = 0; k < kNormalChunkings && nver > 0 && ntri > 0; ++k) {
+    for (int k = 0; k < kNormalChunkings && nver > 0 && ntri > 0 && nver <= 65535; ++k) {
         const int chunks = 1 << k, vpb = (nver + chunks - 1) / chunks;
         std::vector<int> fptr(chunks + 1, 0), slot(face.size(), 0);
         std::vector<std::vector<int4>> lists(chunks);
@@ -695,20 +695,76 @@ dad3d_status dad3d_mesh_create(const int32_t* tri, int ntri, int nver, int devic
             for (int f = 0; f < ntri; ++f)
                 for (int c = 0; c < 3; ++c) slot[cursor[tri[3 * f + c]]++] = pos_of[3 * (size_t)f + c];
         }
+        // The table position of a face is free (a vertex's summation order is the order of its slot row, not of the table):
+        // order every chunk list so that the 32 faces a half-wave crosses together read 32 different LDS banks for each of
+        // their three corners (bank = 3 * index + component mod 32, 3 is invertible mod 32: corner indices distinct mod 32).
+        // First fit over the open groups; what does not fit anywhere goes to the end with its conflicts.
+        for (int ch = 0; ch < chunks; ++ch) {
+            std::vector<int4>& L = lists[ch];
+            const int n = (int)L.size(), ngroups = (n + 31) / 32;
+            std::vector<unsigned> used(3 * (size_t)ngroups, 0u);
+            std::vector<int> fill(ngroups, 0), where(n, -1), spill;
+            int first_open = 0;
+            for (int i = 0; i < n; ++i) {
+                const unsigned b0 = 1u << (L[i].x & 31), b1 = 1u << (L[i].y & 31), b2 = 1u << (L[i].z & 31);
+                int g = first_open, tried = 0;
+                for (; g < ngroups && tried < 64; ++g) {
+                    if (fill[g] >= 32) continue;
+                    ++tried;
+                    if (!(used[3 * g] & b0) && !(used[3 * g + 1] & b1) && !(used[3 * g + 2] & b2)) break;
+                }
+                if (g >= ngroups || tried >= 64) {
+                    spill.push_back(i);
+                    continue;
+                }
+                used[3 * g] |= b0, used[3 * g + 1] |= b1, used[3 * g + 2] |= b2;
+                where[i] = g * 32 + fill[g]++;
+                while (first_open < ngroups && fill[first_open] >= 32) ++first_open;
+            }
+            // full groups first (each lands on a half-wave boundary), then the members of the unfilled groups and the spill
+            std::vector<int> order;  // new position -> old position
+            order.reserve(n);
+            std::vector<std::vector<int>> members(ngroups);
+            for (int i = 0; i < n; ++i)
+                if (where[i] >= 0) members[where[i] / 32].push_back(i);
+            for (int g = 0; g < ngroups; ++g)
+                if (members[g].size() == 32) order.insert(order.end(), members[g].begin(), members[g].end());
+            for (int g = 0; g < ngroups; ++g)
+                if (members[g].size() != 32) order.insert(order.end(), members[g].begin(), members[g].end());
+            order.insert(order.end(), spill.begin(), spill.end());
+            std::vector<int> new_of(n);
+            std::vector<int4> R(n);
+            for (int np = 0; np < n; ++np) new_of[order[np]] = np, R[np] = L[order[np]];
+            L.swap(R);
+            const int lo = ch * vpb, hi = std::min(nver, lo + vpb);
+            for (int v = lo; v < hi; ++v)
+                for (int e = ptr[v]; e < ptr[v + 1]; ++e) slot[e] = new_of[slot[e]];
+        }
         int max_faces = 0;
-        std::vector<int4> flat;
+        std::vector<uint2> flat;
         for (int ch = 0; ch < chunks; ++ch) {
             fptr[ch] = (int)flat.size();
-            flat.insert(flat.end(), lists[ch].begin(), lists[ch].end());
+            for (const int4& f : lists[ch]) flat.push_back(make_uint2((unsigned)f.x | ((unsigned)f.y << 16), (unsigned)f.z));
             max_faces = std::max(max_faces, (int)lists[ch].size());
         }
         fptr[chunks] = (int)flat.size();
-        if (normal_table_lds_bytes(nver, max_faces) > 160 * 1024 - 1024) continue;
-        if ((st = upload(&m->d_nc_faces[k], flat)) || (st = upload(&m->d_nc_ptr[k], fptr)) || (st = upload(&m->d_nc_slot[k], slot))) {
+        if (max_faces > 65535 || normal_table_lds_bytes(nver, max_faces) > 160 * 1024 - 1024) continue;
+        std::vector<unsigned short> slot16(slot.begin(), slot.end());
+        std::vector<uint4> row8(nver);
+        for (int v = 0; v < nver; ++v) {
+            unsigned short r[8];
+            const int deg = ptr[v + 1] - ptr[v];
+            for (int j = 0; j < 8; ++j) r[j] = j < deg ? slot16[ptr[v] + j] : (unsigned short)0xFFFF;
+            if (deg > 8) r[7] = 0xFFFE;
+            row8[v] = make_uint4(r[0] | ((unsigned)r[1] << 16), r[2] | ((unsigned)r[3] << 16), r[4] | ((unsigned)r[5] << 16), r[6] | ((unsigned)r[7] << 16));
+        }
+        if (max_faces >= 0xFFFE) continue;
+        if ((st = upload(&m->d_nc_faces[k], flat)) || (st = upload(&m->d_nc_slot[k], slot16)) || (st = upload(&m->d_nc_row8[k], row8))) {
             dad3d_mesh_destroy(m.release());
             return st;
         }
-        m->nc[k] = NormalChunksDev{m->d_nc_faces[k], m->d_nc_ptr[k], m->d_nc_slot[k], chunks, vpb, max_faces};
+        m->nc[k] = NormalChunksDev{m->d_nc_faces[k], {}, m->d_nc_slot[k], m->d_nc_row8[k], chunks, vpb, max_faces};
+        for (int ch = 0; ch <= chunks; ++ch) m->nc[k].face_ptr[ch] = fptr[ch];
     }
     *out = m.release();
     return DAD3D_OK;
@@ -720,7 +776,7 @@ void dad3d_mesh_destroy(dad3d_mesh* m) {
     for (void* p : {(void*)m->d_tri, (void*)m->d_adj_ptr, (void*)m->d_adj_face, (void*)m->d_adj_tri, m->d_raster})
         if (p) (void)hipFree(p);
     for (int k = 0; k < kNormalChunkings; ++k)
-        for (void* p : {(void*)m->d_nc_faces[k], (void*)m->d_nc_ptr[k], (void*)m->d_nc_slot[k]})
+        for (void* p : {(void*)m->d_nc_faces[k], (void*)m->d_nc_slot[k], (void*)m->d_nc_row8[k]})
             if (p) (void)hipFree(p);
     delete m;
 }
@@ -766,7 +822,7 @@ dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* ve
                   "dad3d_mesh_rasterize: null buffer");
     DeviceGuard guard(m->device);
     if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
-    return launch_rasterize(m->dev(), m->d_raster, m->d_trace, image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse, 0,
+    return launch_rasterize(m->dev(), m->nc, m->d_raster, m->d_trace, image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse, 0,
                             nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -782,7 +838,7 @@ dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* verti
     }
     DAD3D_REQUIRE(vertices && light, "dad3d_mesh_render: null buffer");
     if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
-    return launch_rasterize(m->dev(), m->d_raster, m->d_trace, image, vertices, light, depth, nullptr, nullptr, batch, h, w, 3,
+    return launch_rasterize(m->dev(), m->nc, m->d_raster, m->d_trace, image, vertices, light, depth, nullptr, nullptr, batch, h, w, 3,
                             flags, 0, cfg, static_cast<hipStream_t>(stream));
 }
 
@@ -793,7 +849,7 @@ dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices
     DAD3D_REQUIRE(depth && tri_buf && bary && (vertices || m->ntri == 0), "dad3d_mesh_rasterize_triangles: null buffer");
     DeviceGuard guard(m->device);
     if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
-    return launch_rasterize(m->dev(), m->d_raster, m->d_trace, nullptr, vertices, nullptr, depth, tri_buf, bary, batch, h, w, 3, 0, 1,
+    return launch_rasterize(m->dev(), m->nc, m->d_raster, m->d_trace, nullptr, vertices, nullptr, depth, tri_buf, bary, batch, h, w, 3, 0, 1,
                             nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -868,7 +924,7 @@ dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* ve
     if (batch == 0 || m->nver == 0) return DAD3D_OK;
     DAD3D_REQUIRE(light && vertices && normals, "dad3d_mesh_phong_light: null buffer");
     DeviceGuard guard(m->device);
-    return launch_phong(m->dev(), light, vertices, normals, nullptr, batch, *cfg, static_cast<hipStream_t>(stream));
+    return launch_phong(m->dev(), m->nc, light, vertices, normals, nullptr, batch, *cfg, static_cast<hipStream_t>(stream));
 }
 
 dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* ver_normal, const float* vertices,
@@ -877,7 +933,7 @@ dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* v
     if (batch == 0 || m->nver == 0) return DAD3D_OK;
     DAD3D_REQUIRE(light && vertices, "dad3d_mesh_normal_phong_light: null buffer");
     DeviceGuard guard(m->device);
-    return launch_phong(m->dev(), light, vertices, nullptr, ver_normal, batch, *cfg, static_cast<hipStream_t>(stream));
+    return launch_phong(m->dev(), m->nc, light, vertices, nullptr, ver_normal, batch, *cfg, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

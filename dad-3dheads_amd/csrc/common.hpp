@@ -198,9 +198,12 @@ struct MeshDev {
 // rasterize_kernel.cpp:188-198 -- instead of recomputing every incident face from its corners.
 constexpr int kNormalChunkings = 4;  // 1, 2, 4, 8 chunks per image
 struct NormalChunksDev {
-    const int4* faces;    // [face_ptr[chunks]]  (i0, i1, i2, face), chunk after chunk
-    const int* face_ptr;  // [chunks + 1]
-    const int* slot;      // [3*ntri]  aligned with adj_face: position of adj_face[e] in the list of its vertex's chunk
+    const uint2* faces;   // [face_ptr[chunks]]  (i0 | i1 << 16, i2), chunk after chunk: 8 bytes per face -- these static lists are
+                          // as much load traffic per block as the vertices themselves, hence 16-bit indices
+    int face_ptr[9];      // [chunks + 1] offsets into faces (by value: no dependent round trip in front of the face loads)
+    const unsigned short* slot;  // [3*ntri]  aligned with adj_face: position of adj_face[e] in the list of its vertex's chunk
+    const uint4* row8;    // [nver]  the first eight slots of a vertex as 8 x u16 in ONE aligned 16-byte load (0xFFFF = no more
+                          // faces; a vertex with more than eight keeps seven here and 0xFFFE in the last: the rest from slot[])
     int chunks, vpb, max_faces;  // chunks == 0: not built (mesh too large for the LDS table)
 };
 
@@ -216,10 +219,10 @@ size_t normal_table_lds_bytes(int nver, int max_faces);
 // triangle lists), zeroed once with raster_scratch_init before its first use
 size_t raster_scratch_bytes(const MeshDev& m, int batch, int h, int w);
 dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int h, int w, hipStream_t s);
-dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image, const float* vertices,
+dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc, void* scratch, unsigned long long* trace, uint8_t* image, const float* vertices,
                               const float* colors, float* depth, int32_t* tri_buf, float* bary, int batch, int h,
                               int w, int c, int render_flags, int mode, const dad3d_light* light_cfg, hipStream_t s);
-dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals,
+dad3d_status launch_phong(const MeshDev& m, const NormalChunksDev* nc, float* light, const float* vertices, const float* normals,
                           float* normals_out, int batch, const dad3d_light& cfg, hipStream_t s);
 
 // matrix projection (flame_dataset.py:115-141): frame = [B][3] (image height, crop x, crop y)

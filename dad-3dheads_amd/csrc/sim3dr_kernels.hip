@@ -27,6 +27,10 @@
 
 #include "common.hpp"
 
+#ifndef DAD3D_NT_ABLATE  // diagnostics: 1 no face pass, 2 no table gathers, 4 no staging, 8 no normalisation
+#define DAD3D_NT_ABLATE 0
+#endif
+
 namespace dad3d {
 namespace {
 
@@ -112,6 +116,43 @@ __device__ __forceinline__ float* stage_floats(float* lds, const float* src, int
     if (tid < head) lv[tid] = src[tid];
     const int tail0 = head + 4 * n4;
     if (tid < n - tail0) lv[tail0 + tid] = src[tail0 + tid];
+    return lv;
+}
+
+// The same in two halves, so that a kernel can put the staging loads FIRST in its load queue (vector loads return in issue
+// order: requests issued before them -- face lists, incidence rows -- would hold the staging back by their own round trips):
+// stage_issue requests up to kStagePre float4 per thread, stage_commit writes them (and loops over the rest of a larger array).
+constexpr int kStagePre = 4;  // 4 x 1024 x 16 B = 64 KB: the whole FLAME vertex array
+struct StagePre {
+    float4 q[kStagePre];
+    float head_v, tail_v;
+};
+__device__ __forceinline__ StagePre stage_issue(const float* src, int n, int tid) {
+    StagePre p;
+    const int head = min(n, (int)(((16 - (reinterpret_cast<uintptr_t>(src) & 15)) & 15) >> 2));
+    const int n4 = (n - head) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(src + head);
+#pragma unroll
+    for (int k = 0; k < kStagePre; ++k)
+        p.q[k] = (tid + k * kStageThreads < n4) ? g4[tid + k * kStageThreads] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tail0 = head + 4 * n4;
+    p.head_v = tid < head ? src[tid] : 0.0f;
+    p.tail_v = tid < n - tail0 ? src[tail0 + tid] : 0.0f;
+    return p;
+}
+__device__ __forceinline__ float* stage_commit(float* lds, const float* src, int n, int tid, const StagePre& p) {
+    const int head = min(n, (int)(((16 - (reinterpret_cast<uintptr_t>(src) & 15)) & 15) >> 2));
+    float* lv = lds + ((4 - head) & 3);
+    const int n4 = (n - head) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(src + head);
+    float4* l4 = reinterpret_cast<float4*>(lv + head);
+#pragma unroll
+    for (int k = 0; k < kStagePre; ++k)
+        if (tid + k * kStageThreads < n4) l4[tid + k * kStageThreads] = p.q[k];
+    for (int i = tid + kStagePre * kStageThreads; i < n4; i += kStageThreads) l4[i] = g4[i];
+    if (tid < head) lv[tid] = p.head_v;
+    const int tail0 = head + 4 * n4;
+    if (tid < n - tail0) lv[tail0 + tid] = p.tail_v;
     return lv;
 }
 
@@ -223,44 +264,56 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_lds_kernel(MeshDev m
 // Identical expressions and summation order => identical bits.
 constexpr int kFacesAhead = 4;  // chunk faces of a thread requested before the staging (FLAME, 4 chunks: 3.6 per thread)
 struct SlotRow {
-    int e0, e1;
-    int s[kAdjAhead];
+    uint4 r;  // 8 x u16 table slots; 0xFFFF: none; 0xFFFE in the last: the vertex has more than eight faces
 };
 __device__ __forceinline__ SlotRow load_slot_row(const MeshDev& m, const NormalChunksDev& nc, int v, bool live) {
     SlotRow r;
-    r.e0 = live ? m.adj_ptr[v] : 0;
-    r.e1 = live ? m.adj_ptr[v + 1] : 0;
-#pragma unroll
-    for (int j = 0; j < kAdjAhead; ++j) r.s[j] = (r.e0 + j < r.e1) ? nc.slot[r.e0 + j] : 0;
+    r.r = live ? nc.row8[v] : make_uint4(~0u, ~0u, ~0u, ~0u);
     return r;
 }
 __device__ __forceinline__ int normal_table_offset(int nver) { return (nver * 3 + 8 + 3) & ~3; }  // floats in front of the table
 
-// Phase A: the chunk's face normals into fn[] (caller: barrier afterwards). cf = the thread's first kFacesAhead faces.
+// Phase A: the chunk's face normals into fn[] (caller: barrier afterwards). cf = the thread's first kFacesAhead faces (zeros
+// beyond the list: their corner reads are unconditional so that all of a thread's LDS reads are in flight together).
 __device__ __forceinline__ void fill_face_table(const NormalChunksDev& nc, const float* lv, float4* fn, int f0, int nf,
-                                                const int4 (&cf)[kFacesAhead], int tid) {
-    auto put = [&](int i, const int4& f) {
-        float n[3];
-        face_cross(lv, f.x, f.y, f.z, n);
-        fn[i] = make_float4(n[0], n[1], n[2], 0.0f);
-    };
+                                                const uint2 (&cf)[kFacesAhead], int tid) {
+    float n[kFacesAhead][3];
+#pragma unroll
+    for (int j = 0; j < kFacesAhead; ++j) face_cross(lv, cf[j].x & 0xffff, cf[j].x >> 16, cf[j].y, n[j]);
 #pragma unroll
     for (int j = 0; j < kFacesAhead; ++j)
-        if (tid + j * kStageThreads < nf) put(tid + j * kStageThreads, cf[j]);
-    for (int i = tid + kFacesAhead * kStageThreads; i < nf; i += kStageThreads) put(i, nc.faces[f0 + i]);
+        if (tid + j * kStageThreads < nf) fn[tid + j * kStageThreads] = make_float4(n[j][0], n[j][1], n[j][2], 0.0f);
+    for (int i = tid + kFacesAhead * kStageThreads; i < nf; i += kStageThreads) {
+        const uint2 f = nc.faces[f0 + i];
+        float m3[3];
+        face_cross(lv, f.x & 0xffff, f.x >> 16, f.y, m3);
+        fn[i] = make_float4(m3[0], m3[1], m3[2], 0.0f);
+    }
 }
-// Phase B for one vertex: acc += its incident face normals, ascending face order
-__device__ __forceinline__ void add_table_faces(const NormalChunksDev& nc, const float4* fn, const SlotRow& r, float acc[3]) {
-    auto add = [&](int s) {
-        const float4 n = fn[s];
-        acc[0] += n.x;
-        acc[1] += n.y;
-        acc[2] += n.z;
-    };
+// Phase B for one vertex: acc += its incident face normals, ascending face order. The table entries of the row are read
+// unconditionally (slot 0 where there is none), the additions are conditional: x + 0 is not x for x = -0.
+__device__ __forceinline__ void add_table_faces(const MeshDev& m, const NormalChunksDev& nc, const float4* fn, const SlotRow& r,
+                                                int v, float acc[3]) {
+    const unsigned s[kAdjAhead] = {r.r.x & 0xffff, r.r.x >> 16, r.r.y & 0xffff, r.r.y >> 16,
+                                   r.r.z & 0xffff, r.r.z >> 16, r.r.w & 0xffff, r.r.w >> 16};
+    static_assert(kAdjAhead == 8, "row8 holds eight slots");
+    float4 n[kAdjAhead];
+#pragma unroll
+    for (int j = 0; j < kAdjAhead; ++j) n[j] = fn[s[j] < 0xFFFEu ? s[j] : 0u];
 #pragma unroll
     for (int j = 0; j < kAdjAhead; ++j)
-        if (r.e0 + j < r.e1) add(r.s[j]);
-    for (int e = r.e0 + kAdjAhead; e < r.e1; ++e) add(nc.slot[e]);
+        if (s[j] < 0xFFFEu) {
+            acc[0] += n[j].x;
+            acc[1] += n[j].y;
+            acc[2] += n[j].z;
+        }
+    if (s[kAdjAhead - 1] == 0xFFFEu)  // rare (FLAME: 12 of 5023 vertices): faces 8, 9, ... from the incidence list
+        for (int e = m.adj_ptr[v] + kAdjAhead - 1, e1 = m.adj_ptr[v + 1]; e < e1; ++e) {
+            const float4 q = fn[nc.slot[e]];
+            acc[0] += q.x;
+            acc[1] += q.y;
+            acc[2] += q.z;
+        }
 }
 
 __global__ __launch_bounds__(kStageThreads) void ver_normal_table_kernel(MeshDev m, NormalChunksDev nc, float* ver_normal,
@@ -268,18 +321,20 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_table_kernel(MeshDev
     extern __shared__ __attribute__((aligned(16))) float lds_t[];
     const int tid = threadIdx.x;
     const size_t b = blockIdx.y;
+    // load queue order = arrival order: the vertices first, then the chunk's faces, then the row bounds of the first vertex
+    const StagePre pre = stage_issue(vertices + b * m.nver * 3, m.nver * 3, tid);
     const int f0 = nc.face_ptr[blockIdx.x], nf = nc.face_ptr[blockIdx.x + 1] - f0;
-    int4 cf[kFacesAhead];
+    uint2 cf[kFacesAhead];
 #pragma unroll
     for (int j = 0; j < kFacesAhead; ++j)
-        cf[j] = (tid + j * kStageThreads < nf) ? nc.faces[f0 + tid + j * kStageThreads] : make_int4(0, 0, 0, 0);
+        cf[j] = (tid + j * kStageThreads < nf) ? nc.faces[f0 + tid + j * kStageThreads] : make_uint2(0u, 0u);
     const int v_end = min(m.nver, ((int)blockIdx.x + 1) * nc.vpb);
     const int v0 = blockIdx.x * nc.vpb + tid;
-    SlotRow row = load_slot_row(m, nc, v0, v0 < v_end);  // in flight while the vertices are staged
-    const float* lv = stage_floats(lds_t, vertices + b * m.nver * 3, m.nver * 3, tid);
+    const float* lv = (DAD3D_NT_ABLATE & 4) ? lds_t : stage_commit(lds_t, vertices + b * m.nver * 3, m.nver * 3, tid, pre);
+    SlotRow row = load_slot_row(m, nc, v0, v0 < v_end);  // two dependent round trips, under the barrier and the face pass
     float4* fn = reinterpret_cast<float4*>(lds_t + normal_table_offset(m.nver));
     __syncthreads();
-    fill_face_table(nc, lv, fn, f0, nf, cf, tid);
+    if (!(DAD3D_NT_ABLATE & 1)) fill_face_table(nc, lv, fn, f0, nf, cf, tid);
     __syncthreads();
     for (int v = v0; v < v_end; v += kStageThreads) {
         const SlotRow cur = row;
@@ -287,8 +342,9 @@ __global__ __launch_bounds__(kStageThreads) void ver_normal_table_kernel(MeshDev
         float* d = ver_normal + (b * m.nver + v) * 3;
         float acc[3] = {0.0f, 0.0f, 0.0f};
         if (flags & DAD3D_NORMAL_ACCUMULATE) acc[0] = d[0], acc[1] = d[1], acc[2] = d[2];
-        add_table_faces(nc, fn, cur, acc);
-        unit3(acc);
+        if (!(DAD3D_NT_ABLATE & 2)) add_table_faces(m, nc, fn, cur, v, acc);
+        if (DAD3D_NT_ABLATE & 2) acc[0] = (float)cur.r.x, acc[1] = (float)cur.r.w;
+        if (!(DAD3D_NT_ABLATE & 8)) unit3(acc);
         d[0] = acc[0];
         d[1] = acc[1];
         d[2] = acc[2];
@@ -302,10 +358,14 @@ __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 
 
 // Lights the vertices [v0, v_end) of image b (stride kStageThreads): lv = the image's vertices in LDS (already staged and
 // barrier-ed), red = 6 x 16 floats of LDS scratch, row = the prefetched incidence row of vertex v0 (FUSE_NORMALS).
-template <bool FUSE_NORMALS>
-__device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const float* lv, float (*red)[kStageThreads / 64], size_t b,
-                                                  int v0, int v_end, AdjRow row, float* light, const float* normals,
-                                                  float* normals_out, int nver, const dad3d_light& cfg) {
+// NORMALS: 0 = read them from `normals`, 1 = gather the incident faces from their corners (row), 2 = sum the entries of the
+// face-normal table `fn` the caller has filled (srow; the barrier behind the bounds reduction orders the table)
+template <int NORMALS>
+__device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const NormalChunksDev& nc, const float* lv, const float4* fn,
+                                                  float (*red)[kStageThreads / 64], size_t b, int v0, int v_end, AdjRow row,
+                                                  SlotRow srow, float* light, const float* normals, float* normals_out,
+                                                  int nver, const dad3d_light& cfg) {
+    constexpr bool FUSE_NORMALS = NORMALS != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float bd[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int u = tid; u < nver; u += kStageThreads)
@@ -339,9 +399,14 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const float*
     }
     for (int v = v0; v < v_end; v += kStageThreads) {
     AdjRow cur;
-    if (FUSE_NORMALS) {
+    SlotRow scur;
+    if (NORMALS == 1) {
         cur = row;
         row = load_adj_row(m, v + kStageThreads, v + kStageThreads < v_end);
+    }
+    if (NORMALS == 2) {
+        scur = srow;
+        srow = load_slot_row(m, nc, v + kStageThreads, v + kStageThreads < v_end);
     }
     float vn[3], n[3];
 #pragma unroll
@@ -352,7 +417,8 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const float*
         n[k] = FUSE_NORMALS ? 0.0f : normals[(b * nver + v) * 3 + k];
     }
     if (FUSE_NORMALS) {
-        add_incident_faces(m, lv, cur, n);
+        if (NORMALS == 1) add_incident_faces(m, lv, cur, n);
+        if (NORMALS == 2) add_table_faces(m, nc, fn, scur, v, n);
         unit3(n);
         if (normals_out)
 #pragma unroll
@@ -396,8 +462,8 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const float*
 // min / max of the whole image itself (norm_vertices, lighting.py:9-14: exact whatever the reduction order), then lights
 // its chunk. FUSE_NORMALS: the vertex normals are computed here from the staged vertices (_get_normal on a zeroed
 // buffer, as RenderPipeline does, lighting.py:64-66) instead of being read back; `normals_out` (optional) gets them.
-template <bool FUSE_NORMALS>
-__global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* light, const float* vertices,
+template <int NORMALS>
+__global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, NormalChunksDev nc, float* light, const float* vertices,
                                                               const float* normals, float* normals_out, int nver,
                                                               dad3d_light cfg, int verts_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds_p[];
@@ -407,10 +473,22 @@ __global__ __launch_bounds__(kStageThreads) void phong_kernel(MeshDev m, float* 
     const int v_end = min(nver, ((int)blockIdx.x + 1) * verts_per_block);
     const int v0 = blockIdx.x * verts_per_block + tid;
     AdjRow row{};
-    if (FUSE_NORMALS) row = load_adj_row(m, v0, v0 < v_end);  // in flight while the vertices are staged
+    SlotRow srow{};
+    uint2 cf[kFacesAhead];
+    int f0 = 0, nf = 0;
+    if (NORMALS == 1) row = load_adj_row(m, v0, v0 < v_end);  // in flight while the vertices are staged
+    if (NORMALS == 2) {
+        f0 = nc.face_ptr[blockIdx.x], nf = nc.face_ptr[blockIdx.x + 1] - f0;
+#pragma unroll
+        for (int j = 0; j < kFacesAhead; ++j)
+            cf[j] = (tid + j * kStageThreads < nf) ? nc.faces[f0 + tid + j * kStageThreads] : make_uint2(0u, 0u);
+        srow = load_slot_row(m, nc, v0, v0 < v_end);
+    }
     const float* lv = stage_floats(lds_p, vertices + b * nver * 3, nver * 3, tid);
+    float4* fn = reinterpret_cast<float4*>(lds_p + normal_table_offset(nver));
     __syncthreads();
-    phong_light_chunk<FUSE_NORMALS>(m, lv, red, b, v0, v_end, row, light, normals, normals_out, nver, cfg);
+    if (NORMALS == 2) fill_face_table(nc, lv, fn, f0, nf, cf, tid);
+    phong_light_chunk<NORMALS>(m, nc, lv, fn, red, b, v0, v_end, row, srow, light, normals, normals_out, nver, cfg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -580,9 +658,10 @@ struct LightJob {
     dad3d_light cfg;
     uint4* clear;        // RenderPipeline on a black background: the image buffer, zeroed by this launch (16-byte aligned) ...
     size_t clear_vec16;  // ... its size in 16-byte units, or 0
+    NormalChunksDev nc;  // WITH_LIGHT == 2: blocks [0, nc.chunks) of an image light one vertex chunk each through the face table
 };
 
-template <bool LDS_VERTS, bool WITH_LIGHT>
+template <bool LDS_VERTS, int WITH_LIGHT>
 __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, const float* vertices, RasterScratch sc,
                                                                    int h, int w, LightJob job) {
     extern __shared__ __attribute__((aligned(16))) float lds_v[];
@@ -599,15 +678,34 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
         const size_t per = (job.clear_vec16 + nblk - 1) / nblk, end = min(job.clear_vec16, (bid + 1) * per);
         for (size_t i = bid * per + tid; i < end; i += kGeoThreads) job.clear[i] = make_uint4(0u, 0u, 0u, 0u);
     }
+    // WITH_LIGHT == 2: the chunk's faces and the first incidence row are requested before the staging
+    const bool light_here = WITH_LIGHT == 2 && (int)blockIdx.x < job.nc.chunks;  // block-uniform
+    uint2 cf[kFacesAhead];
+    SlotRow srow{};
+    int lf0 = 0, lnf = 0, lv0 = 0, lv_end = 0;
+    if (light_here) {
+        lf0 = job.nc.face_ptr[blockIdx.x], lnf = job.nc.face_ptr[blockIdx.x + 1] - lf0;
+#pragma unroll
+        for (int j = 0; j < kFacesAhead; ++j)
+            cf[j] = (tid + j * kStageThreads < lnf) ? job.nc.faces[lf0 + tid + j * kStageThreads] : make_uint2(0u, 0u);
+        lv0 = blockIdx.x * job.nc.vpb + tid, lv_end = min(m.nver, ((int)blockIdx.x + 1) * job.nc.vpb);
+        srow = load_slot_row(m, job.nc, lv0, lv0 < lv_end);
+    }
     const float* lv = LDS_VERTS ? stage_floats(lds_v, vb, n, tid) : nullptr;
     __syncthreads();
-    if (WITH_LIGHT) {
+    if (WITH_LIGHT == 1) {
         static_assert(!WITH_LIGHT || LDS_VERTS, "lighting needs the staged vertices");
         __shared__ float red[6][kStageThreads / 64];
         const int vpb = (m.nver + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lv0 = blockIdx.x * vpb + tid, lv_end = min(m.nver, ((int)blockIdx.x + 1) * vpb);
-        phong_light_chunk<true>(m, lv, red, b, lv0, lv_end, load_adj_row(m, lv0, lv0 < lv_end), job.light, nullptr, nullptr,
-                                m.nver, job.cfg);
+        phong_light_chunk<1>(m, job.nc, lv, nullptr, red, b, lv0, lv_end, load_adj_row(m, lv0, lv0 < lv_end), SlotRow{}, job.light,
+                             nullptr, nullptr, m.nver, job.cfg);
+    }
+    if (light_here) {  // block-uniform: the barriers inside are safe
+        __shared__ float red2[6][kStageThreads / 64];
+        float4* fn = reinterpret_cast<float4*>(cnt + ((2 * ntiles + 3) & ~3));  // behind the counters, 16-byte aligned
+        fill_face_table(job.nc, lv, fn, lf0, lnf, cf, tid);
+        phong_light_chunk<2>(m, job.nc, lv, fn, red2, b, lv0, lv_end, AdjRow{}, srow, job.light, nullptr, nullptr, m.nver, job.cfg);
     }
     auto coord = [&](int e) { return LDS_VERTS ? lv[e] : vb[e]; };
     const size_t nt = m.ntri;
@@ -1280,7 +1378,7 @@ dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int
     return DAD3D_OK;
 }
 
-dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long long* trace, uint8_t* image,
+dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc_all, void* scratch, unsigned long long* trace, uint8_t* image,
                               const float* vertices, const float* colors, float* depth, int32_t* tri_buf, float* bary,
                               int batch, int h, int w, int c, int render_flags, int mode, const dad3d_light* light_cfg,
                               hipStream_t s) {
@@ -1297,9 +1395,11 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
     const int cur_dev = PerDeviceOnce::current();
     constexpr int kMaxLds = 160 * 1024 - 1024;  // dynamic part: the geometry kernel also has some static words
     if (!raster_attr_done.done(cur_dev)) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, false>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, true>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_geometry_kernel<true, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         int dev = 0, cus = 0, per_cu[2] = {0, 0};
         DAD3D_HIP_TRY(hipGetDevice(&dev));
@@ -1321,6 +1421,15 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
         const size_t cnt_bytes = std::max<size_t>(2 * (size_t)ntiles, kQueueBuckets) * sizeof(unsigned);  // counters, later the queue histogram
         const size_t vlds = ((size_t)m.nver * 3 + 12) * sizeof(float) + cnt_bytes;
         LightJob job{};
+        // lighting through the face-normal table: the finest chunking that has a block for every chunk, if its table fits
+        const NormalChunksDev* lnc = nullptr;
+        size_t tlds = 0;
+        if (light_cfg && nc_all && !(DAD3D_NORMALS_OLD))
+            for (int k = kNormalChunkings - 1; k >= 0 && !lnc; --k) {
+                tlds = (((size_t)m.nver * 3 + 12 + 3) & ~(size_t)3) * sizeof(float) + ((2 * (size_t)ntiles + 3) & ~(size_t)3) * sizeof(unsigned) +
+                       16 * (size_t)nc_all[k].max_faces + 64;
+                if (nc_all[k].chunks && nc_all[k].chunks <= (int)ggrid.x && tlds <= (size_t)kMaxLds) lnc = &nc_all[k];
+            }
         if (light_cfg) {  // colours = per-vertex Phong light computed by the geometry kernel itself
             DAD3D_REQUIRE(vlds <= (size_t)kMaxLds && c == 3 && mode == 0, "render: needs a 3-channel image and a mesh that fits the LDS");
             job.light = const_cast<float*>(colors);
@@ -1334,11 +1443,16 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
                     DAD3D_HIP_TRY(hipMemsetAsync(image, 0, bytes, s));
                 }
             }
-            hipLaunchKernelGGL((tri_geometry_kernel<true, true>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
+            if (lnc) {
+                job.nc = *lnc;
+                hipLaunchKernelGGL((tri_geometry_kernel<true, 2>), ggrid, dim3(kGeoThreads), std::max(vlds, tlds), s, m, vertices, sc, h, w, job);
+            } else {
+                hipLaunchKernelGGL((tri_geometry_kernel<true, 1>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
+            }
         } else if (vlds <= (size_t)kMaxLds) {
-            hipLaunchKernelGGL((tri_geometry_kernel<true, false>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
+            hipLaunchKernelGGL((tri_geometry_kernel<true, 0>), ggrid, dim3(kGeoThreads), vlds, s, m, vertices, sc, h, w, job);
         } else {
-            hipLaunchKernelGGL((tri_geometry_kernel<false, false>), ggrid, dim3(kGeoThreads), 48 + cnt_bytes, s, m, vertices, sc, h, w, job);
+            hipLaunchKernelGGL((tri_geometry_kernel<false, 0>), ggrid, dim3(kGeoThreads), 48 + cnt_bytes, s, m, vertices, sc, h, w, job);
         }
         DAD3D_HIP_TRY(hipGetLastError());
     }
@@ -1353,7 +1467,7 @@ dad3d_status launch_rasterize(const MeshDev& m, void* scratch, unsigned long lon
 }
 
 // normals == nullptr: compute them in the same launch (normals_out optional); else light from the given normals
-dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices, const float* normals,
+dad3d_status launch_phong(const MeshDev& m, const NormalChunksDev* nc_all, float* light, const float* vertices, const float* normals,
                           float* normals_out, int batch, const dad3d_light& cfg, hipStream_t s) {
     if (batch == 0 || m.nver == 0) return DAD3D_OK;
     const size_t lds = ((size_t)m.nver * 3 + 8) * sizeof(float);
@@ -1361,20 +1475,26 @@ dad3d_status launch_phong(const MeshDev& m, float* light, const float* vertices,
     static PerDeviceOnce attr_done;
     const int dev = PerDeviceOnce::current();
     if (!attr_done.done(dev)) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<false>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<true>),
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phong_kernel<2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds - 1024));
         attr_done.set(dev);
     }
     const int vpb = staged_verts_per_block(m.nver, batch);
     const dim3 grid((m.nver + vpb - 1) / vpb, batch);
+    const NormalChunksDev* nc = (normals || DAD3D_NORMALS_OLD) ? nullptr : pick_normal_chunks(nc_all, m.nver, batch);
     if (normals)
-        hipLaunchKernelGGL(phong_kernel<false>, grid, dim3(kStageThreads), lds, s, m, light, vertices, normals, nullptr,
-                           m.nver, cfg, vpb);
+        hipLaunchKernelGGL(phong_kernel<0>, grid, dim3(kStageThreads), lds, s, m, NormalChunksDev{}, light, vertices, normals,
+                           nullptr, m.nver, cfg, vpb);
+    else if (nc)
+        hipLaunchKernelGGL(phong_kernel<2>, dim3(nc->chunks, batch), dim3(kStageThreads), normal_table_lds_bytes(m.nver, nc->max_faces),
+                           s, m, *nc, light, vertices, nullptr, normals_out, m.nver, cfg, nc->vpb);
     else
-        hipLaunchKernelGGL(phong_kernel<true>, grid, dim3(kStageThreads), lds, s, m, light, vertices, nullptr, normals_out,
-                           m.nver, cfg, vpb);
+        hipLaunchKernelGGL(phong_kernel<1>, grid, dim3(kStageThreads), lds, s, m, NormalChunksDev{}, light, vertices, nullptr,
+                           normals_out, m.nver, cfg, vpb);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }
