@@ -64,13 +64,19 @@ __device__ __forceinline__ TriSetup tri_setup(float x0, float y0, float x1, floa
     return t;
 }
 
-// TriSetup from a record (the dot products are not stored: same expressions as tri_setup, so the same bits)
-__device__ __forceinline__ TriSetup setup_from_record(const float4& r0, const float4& r1) {
+// TriSetup from the corners and the stored inv: the expressions of tri_setup without its division, so the same bits
+__device__ __forceinline__ TriSetup setup_from_corners(float x0, float y0, float x1, float y1, float x2, float y2, float inv) {
     TriSetup t;
-    t.x0 = r0.x, t.y0 = r0.y, t.ax = r0.z, t.ay = r0.w, t.bx = r1.x, t.by = r1.y, t.inv = r1.z;
+    t.x0 = x0;
+    t.y0 = y0;
+    t.ax = x2 - x0;
+    t.ay = y2 - y0;
+    t.bx = x1 - x0;
+    t.by = y1 - y0;
     t.d00 = t.ax * t.ax + t.ay * t.ay;
     t.d01 = t.ax * t.bx + t.ay * t.by;
     t.d11 = t.bx * t.bx + t.by * t.by;
+    t.inv = inv;
     return t;
 }
 
@@ -530,10 +536,11 @@ constexpr int kListCap = 8 * kRasterThreads;  // list entries sorted per round (
 constexpr int kListPerThread = kListCap / kRasterThreads;
 constexpr int kClasses = 12;         // box area <=2, <=4, <=8, <=16, ... <=4096 (= a whole tile)
 constexpr int kSpread = 16;          // copies of every class counter: 64 lanes hit 16 addresses instead of one
-constexpr int kRecF4 = 3;            // one 48-byte record per (image, triangle): x0 y0 ax ay | bx by inv z0 |
-                                     // z1 z2 box.x box.y -- read as 3 x b128. The dot products d00 d01 d11 of TriSetup are
-                                     // recomputed by the reader (9 ALU ops, the same expressions: identical bits): the
-                                     // record stream is the largest cost of the geometry kernel and of the resolve
+// One 12-byte record per (image, on-screen triangle): inv of get_point_weight's pixel-independent half and the screen box
+// exactly as rasterize_kernel.cpp:246-254 clips it (x0 | x1 << 16, y0 | y1 << 16). Rounds 1-2 kept a 48-byte record
+// (corner, edge vectors, inv, depths, box): 24-30 MB written by the geometry kernel and read back by the tile kernel, the
+// largest cost of the former. Everything but inv and the box is a few subtractions away from the three corners, which the
+// tile kernel now gathers from the image's vertex array (60 KB per image: L1 / L2 resident) through the static index list.
 constexpr int kGeoThreads = kStageThreads;
 constexpr int kGeoPerThread = 3;
 constexpr int kGeoTrisPerBlock = kGeoThreads * kGeoPerThread;
@@ -564,9 +571,11 @@ __device__ __forceinline__ int area_class(int area) {
     return min(max(31 - __clz(max(area - 1, 1)) - (area <= 2 ? 1 : 0), 0), kClasses - 1);
 }
 
+typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+
 struct RasterScratch {
-    float4* rec;        // [B][ntri][3]   corner 0, edge vectors, inv, corner depths, screen box (x0 | x1 << 16,
-                        //                y0 | y1 << 16) of every on-screen triangle
+    float3u* rec;       // [B][ntri]   inv, screen box (x0 | x1 << 16, y0 | y1 << 16) of every on-screen triangle
     unsigned* counts;   // [2][B * ntiles]  triangles in a tile list, then the sum of their box areas inside the tile;
                         //                  zero between launches (the queue kernel resets them)
     unsigned* lists;    // [B * ntiles][ntri]   triangle | area class within the tile << 28
@@ -643,6 +652,9 @@ __device__ void build_work_queue(const RasterScratch& sc, int n_lists, unsigned*
 
 #ifndef DAD3D_NORMALS_OLD  // diagnostics: 1 = the per-vertex cross-product kernel of rounds 1-2
 #define DAD3D_NORMALS_OLD 0
+#endif
+#ifndef DAD3D_RASTER_TRACE  // 1: the per-phase stamps and walk statistics of tools/raster_probe.py (dad3d_mesh_debug_trace); costs
+#define DAD3D_RASTER_TRACE 0  // registers and a scalar branch per pixel test, so the product is built without
 #endif
 #ifndef DAD3D_RK_ABLATE  // diagnostics only: 1 no fragment walk, 2 no resolve, 4 resolve without colour gathers, 8 without records
 #define DAD3D_RK_ABLATE 0
@@ -730,13 +742,12 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
         if (bx1 < bx0 || by1 < by0) bx0 = by0 = 1, bx1 = by1 = 0;  // `continue` in the reference: empty box
         box[k] = make_uint2((unsigned)bx0 | ((unsigned)bx1 << 16), (unsigned)by0 | ((unsigned)by1 << 16));
         const TriSetup ts = tri_setup(x0, y0, x1, y1, x2, y2);
-        float4* rp = sc.rec + (b * nt + f) * kRecF4;
-        // records are only ever read through the tile lists: an off-screen triangle (a fifth of a head that fills
-        // the frame) is in none and needs none -- the record stream is the largest cost of this kernel
-        if ((bx0 <= bx1 && !(DAD3D_K1_ABLATE & 4)) || ts.inv == 12345.0f) {
-            rp[0] = make_float4(ts.x0, ts.y0, ts.ax, ts.ay);
-            rp[1] = make_float4(ts.bx, ts.by, ts.inv, z0);
-            rp[2] = make_float4(z1, z2, __uint_as_float(box[k].x), __uint_as_float(box[k].y));
+        // records are only ever read through the tile lists: an off-screen triangle (a fifth of a head that fills the
+        // frame) is in none and needs none
+        if (bx0 <= bx1 && !(DAD3D_K1_ABLATE & 4)) {
+            float3u r;
+            r.x = ts.inv, r.y = __uint_as_float(box[k].x), r.z = __uint_as_float(box[k].y);
+            sc.rec[b * nt + f] = r;
         }
         if (bx0 <= bx1 && !(DAD3D_K1_ABLATE & 1))
             for (int ty = by0 >> kTileShift; ty <= by1 >> kTileShift; ++ty)
@@ -787,13 +798,12 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     if (tid == 0) sc.qhdr[2] = 0;
 }
 
-typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
-typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
 
 struct RasterArgs {
     MeshDev m;
     RasterScratch sc;
     uint8_t* image;
+    const float* vertices;
     const float* colors;
     float* depth;
     int32_t* tri_buf;
@@ -846,22 +856,25 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     // grid) by thread 0 when the walk is over, so that the round trip hides under the resolve.
     unsigned item = blockIdx.x;
     uint2 qe = item < n_items ? a.sc.queue[item] : make_uint2(0u, 0u);
+    qe = make_uint2((unsigned)__builtin_amdgcn_readfirstlane((int)qe.x), (unsigned)__builtin_amdgcn_readfirstlane((int)qe.y));
     for (;;) {
     if (item >= n_items) break;
     const int level = (qe.x >> 24) & 3, part = qe.x >> 26, n_total = (int)qe.y;
-    const size_t b = (qe.x & 0xFFFFFFu) / ntiles;
-    const int tile = (qe.x & 0xFFFFFFu) % ntiles;
+    // (integer division runs on the vector unit even for uniform operands: back to scalar registers by hand)
+    const size_t b = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((qe.x & 0xFFFFFFu) / ntiles));
+    const int tile = __builtin_amdgcn_readfirstlane((int)((qe.x & 0xFFFFFFu) % ntiles));
     // the item's pixel rectangle: the whole tile or one of its 2x2 / 4x4 parts
     const int edge = kTile >> level, edge_shift = kTileShift - level;  // 64, 32 or 16 pixels: rows by shifts, not divisions
-    const int tx0 = (tile % a.sc.tiles_x) * kTile + (part & ((1 << level) - 1)) * edge;
-    const int ty0 = (tile / a.sc.tiles_x) * kTile + (part >> level) * edge;
+    const int tx0 = __builtin_amdgcn_readfirstlane((tile % a.sc.tiles_x) * kTile + (part & ((1 << level) - 1)) * edge);
+    const int ty0 = __builtin_amdgcn_readfirstlane((tile / a.sc.tiles_x) * kTile + (part >> level) * edge);
     const int tw = min(edge, a.w - tx0), th = min(edge, a.h - ty0);
     const int tx1 = tx0 + tw - 1, ty1 = ty0 + th - 1;
-    const float4* rec_b = a.sc.rec + b * nt * kRecF4;
+    const float3u* rec_b = a.sc.rec + b * nt;
+    const float* vb = a.vertices + b * a.m.nver * 3;
     const unsigned* glist = a.sc.lists + (b * ntiles + tile) * nt;
     float* depth_b = a.depth ? a.depth + b * a.h * a.w : nullptr;
     auto stamp = [&](int slot) {
-        if (a.trace && lane == 0) a.trace[((size_t)item * kRasterWaves + (tid >> 6)) * 16 + slot] = wall_clock64();
+        if (DAD3D_RASTER_TRACE && a.trace && lane == 0) a.trace[((size_t)item * kRasterWaves + (tid >> 6)) * 16 + slot] = wall_clock64();
     };
     stamp(0);
     if (tw > 0 && th > 0) {  // a part can lie beyond the image edge
@@ -871,7 +884,7 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
 #pragma unroll
     for (int k = 0; k < kListPerThread; ++k) {
         const int i = k * kRasterThreads + tid;
-        first_entries[k] = i < min(kListCap, n_total) ? glist[i] : ~0u;
+        first_entries[k] = i < min(kListCap, n_total) ? glist[(unsigned)i] : ~0u;
     }
     for (int p = tid; p < edge * th; p += kRasterThreads) {
         const int ly = p >> edge_shift, lx = p & (edge - 1);
@@ -882,8 +895,8 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
 
     stamp(12);
     // (A) list entries [r * kListCap, ...) -> slist sorted by class of the box area inside the item
-    auto clipped_area = [&](float4 r2) {
-        const unsigned bx = __float_as_uint(r2.z), by = __float_as_uint(r2.w);
+    auto clipped_area = [&](float3u r2) {
+        const unsigned bx = __float_as_uint(r2.y), by = __float_as_uint(r2.z);
         const int x0 = max((int)(bx & 0xffff), tx0), x1 = min((int)(bx >> 16), tx1);
         const int y0 = max((int)(by & 0xffff), ty0), y1 = min((int)(by >> 16), ty1);
         return (x1 < x0 || y1 < y0) ? 0 : (x1 - x0 + 1) * (y1 - y0 + 1);
@@ -892,23 +905,21 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
         const int n = min(kListCap, n_total - r * kListCap);
         for (int i = tid; i < kClasses * kSpread; i += kRasterThreads) (&ccount[0][0])[i] = 0;
         __syncthreads();
-        unsigned fv[kListPerThread];
-        int cl[kListPerThread];
+        // one register per entry: triangle | class << 28, or ~0u for "not in this item" (class 15 is never a real class)
+        unsigned ent[kListPerThread];
         const int copy = lane & (kSpread - 1);
 #pragma unroll
         for (int k = 0; k < kListPerThread; ++k) {
             const int i = k * kRasterThreads + tid;
-            cl[k] = -1;
-            const unsigned e = r == 0 ? first_entries[k] : i < n ? glist[r * kListCap + i] : ~0u;
+            unsigned e = r == 0 ? first_entries[k] : i < n ? glist[(unsigned)(r * kListCap + i)] : ~0u;
             if (e != ~0u) {
-                fv[k] = e & kIdMask;
-                cl[k] = (int)(e >> 28);
                 if (level > 0) {  // a part of the tile: drop the triangles that miss it, re-class the others
-                    const int area = clipped_area(rec_b[(size_t)fv[k] * kRecF4 + 2]);
-                    cl[k] = area > 0 ? area_class(area) : -1;
+                    const int area = clipped_area(rec_b[e & kIdMask]);
+                    e = area > 0 ? (e & kIdMask) | ((unsigned)area_class(area) << 28) : ~0u;
                 }
-                if (cl[k] >= 0) atomicAdd(&ccount[cl[k]][copy], 1);
+                if (e != ~0u) atomicAdd(&ccount[e >> 28][copy], 1);
             }
+            ent[k] = e;
         }
         __syncthreads();
         if (r == 0) stamp(13);
@@ -944,35 +955,45 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
         if (r == 0) stamp(14);
 #pragma unroll
         for (int k = 0; k < kListPerThread; ++k)
-            if (cl[k] >= 0) slist[atomicAdd(&ccount[cl[k]][copy], 1)] = fv[k];
+            if (ent[k] != ~0u) slist[atomicAdd(&ccount[ent[k] >> 28][copy], 1)] = ent[k] & kIdMask;
         __syncthreads();
     };
 
     // Walk over the lane slots of the sorted list: pixel(t, x, y) per box pixel assigned to the lane (the lanes of a
     // triangle stride over its row-major box).
     // The record of the next wave step is requested before the pixels of the current one are worked on.
+    // A step's data arrives in two dependent requests -- triangle -> corner indices + record, then the three corners -- each
+    // issued one step's work ahead of its use: three slots rotate (working on one, corners of the next in flight, indices
+    // of the one after in flight).
     struct Slot {
-        float4 r0, r1, r2;
-        int f, sub, lg;
-        bool valid;
+        float3u c0, c1, c2, rc;
+        int3u idx;
+        unsigned fl;  // triangle | log2(lanes of the triangle) << 28, or kNoTri: nothing to do
+        int sub;
     };
     auto walk = [&](int trace_base, auto&& pixel) {
         const int n_slots = __builtin_amdgcn_readfirstlane(sbase[kClasses]);
         // lane k - 1 keeps the first slot of class k: the class of a wave step is a ballot and a population count
         const int class_start = (lane < kClasses - 1) ? sbase[lane + 1] : INT_MAX;
-        auto fetch = [&](int s0, Slot& sl) {  // s0 is wave-uniform
-            sl.valid = false;
+        auto fetch1 = [&](int s0, Slot& sl) {  // s0 is wave-uniform
+            sl.fl = kNoTri;
             if (s0 >= n_slots) return;
             const int c = __builtin_popcountll(__ballot(s0 >= class_start));
-            sl.lg = max(c - kLaneShift, 0);
+            const int lg = max(c - kLaneShift, 0);
             const int local = s0 + lane - sbase[c];
-            const int ti = local >> sl.lg;
-            sl.sub = local & ((1 << sl.lg) - 1);
+            const int ti = local >> lg;
+            sl.sub = local & ((1 << lg) - 1);
             if (ti >= cnum[c]) return;
-            sl.f = (int)slist[cbase[c] + ti];
-            const float4* rp = rec_b + (size_t)sl.f * kRecF4;
-            sl.r0 = rp[0], sl.r1 = rp[1], sl.r2 = rp[2];
-            sl.valid = true;
+            const unsigned f = slist[cbase[c] + ti];
+            sl.idx = *reinterpret_cast<const int3u*>(a.m.tri + 3 * (size_t)f);
+            sl.fl = f | ((unsigned)lg << 28);
+        };
+        auto fetch2 = [&](Slot& sl) {
+            if (sl.fl == kNoTri) return;
+            sl.rc = rec_b[sl.fl & kIdMask];  // with the corners, not with the indices: three registers less across a step
+            sl.c0 = *reinterpret_cast<const float3u*>(vb + 3 * (size_t)sl.idx.x);
+            sl.c1 = *reinterpret_cast<const float3u*>(vb + 3 * (size_t)sl.idx.y);
+            sl.c2 = *reinterpret_cast<const float3u*>(vb + 3 * (size_t)sl.idx.z);
         };
         // waves take steps from an LDS counter: a step costs 1 to 8 pixel tests per lane, mostly outside or mostly
         // inside its triangle, so a fixed assignment left some waves with twice the work of others
@@ -984,27 +1005,28 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
         unsigned d_steps = 0, d_wait = 0, d_work = 0, d_trips = 0;  // diagnostics (a.trace only)
         auto work = [&](const Slot& cur) {
             unsigned c0 = 0, c1 = 0;
-            if (a.trace) {
+            if (DAD3D_RASTER_TRACE && a.trace) {
                 c0 = (unsigned)wall_clock64();
                 __builtin_amdgcn_s_waitcnt(0);
                 c1 = (unsigned)wall_clock64();
                 d_wait += c1 - c0, ++d_steps;
             }
-            if (cur.valid) {
+            if (cur.fl != kNoTri) {
                 TriLane t;
-                t.f = cur.f;
-                t.ts = setup_from_record(cur.r0, cur.r1);
-                t.z0 = cur.r1.w, t.z1 = cur.r2.x, t.z2 = cur.r2.y;
-                const unsigned bbx = __float_as_uint(cur.r2.z), bby = __float_as_uint(cur.r2.w);
+                t.f = (int)(cur.fl & kIdMask);
+                const int cur_lg = (int)(cur.fl >> 28);
+                t.ts = setup_from_corners(cur.c0.x, cur.c0.y, cur.c1.x, cur.c1.y, cur.c2.x, cur.c2.y, cur.rc.x);
+                t.z0 = cur.c0.z, t.z1 = cur.c1.z, t.z2 = cur.c2.z;
+                const unsigned bbx = __float_as_uint(cur.rc.y), bby = __float_as_uint(cur.rc.z);
                 t.bx0 = max((int)(bbx & 0xffff), tx0);
                 t.by0 = max((int)(bby & 0xffff), ty0);
                 const int bw = min((int)(bbx >> 16), tx1) - t.bx0 + 1, bh = min((int)(bby >> 16), ty1) - t.by0 + 1;
                 // The lane's pixels are box entries sub, sub + g, ... (row-major). Their coordinates are carried as floats
                 // (exact: integers below 2^16) so that a step is two adds and a wrap, and the walk ends when the row
                 // index reaches the box height (index < area <=> row < bh).
-                const int g = 1 << cur.lg;
+                const int g = 1 << cur_lg;
                 int x, y, gq, gr;
-                if (cur.lg == 0) {  // wave-uniform: one lane per triangle, entry 0, stride 1
+                if (cur_lg == 0) {  // wave-uniform: one lane per triangle, entry 0, stride 1
                     x = 0, y = 0, gq = bw == 1 ? 1 : 0, gr = bw == 1 ? 0 : 1;
                 } else {
                     const float rcp_bw = __builtin_amdgcn_rcpf((float)bw);
@@ -1018,26 +1040,35 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
                     pixel(t, px, py);
                     px += fgr, py += fgq;
                     if (px >= x_end) px -= fbw, py += 1.0f;
-                    if (a.trace) ++d_trips;
+                    if (DAD3D_RASTER_TRACE && a.trace) ++d_trips;
                 }
             }
-            if (a.trace) d_work += (unsigned)wall_clock64() - c1;
+            if (DAD3D_RASTER_TRACE && a.trace) d_work += (unsigned)wall_clock64() - c1;
         };
-        // two slots used alternately (the record of the next step is in flight while the current one is worked on):
-        // no register copies between steps
-        Slot even, odd;
-        int s0 = next_step();
-        fetch(s0, even);
-        while (s0 < n_slots) {
-            s0 = next_step();
-            fetch(s0, odd);
-            work(even);
-            if (s0 >= n_slots) break;
-            s0 = next_step();
-            fetch(s0, even);
-            work(odd);
+        Slot sa, sb, sc3;
+        int ia = next_step();
+        fetch1(ia, sa);
+        int ib = next_step();
+        fetch1(ib, sb);
+        fetch2(sa);
+        for (;;) {
+            if (ia >= n_slots) break;
+            int ic = next_step();
+            fetch1(ic, sc3);
+            fetch2(sb);
+            work(sa);
+            if (ib >= n_slots) break;
+            ia = next_step();
+            fetch1(ia, sa);
+            fetch2(sc3);
+            work(sb);
+            if (ic >= n_slots) break;
+            ib = next_step();
+            fetch1(ib, sb);
+            fetch2(sa);
+            work(sc3);
         }
-        if (a.trace) {
+        if (DAD3D_RASTER_TRACE && a.trace) {
             unsigned mx = d_trips;
             for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
             if (lane == 0) {
@@ -1106,25 +1137,31 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
         constexpr int NP = 2;  // pixels per lane in flight
         const int nc = C ? C : a.c;
         const int npix = edge * th;
-        // A lane's pixels are p = tid + k * 512, k < 8. The corner indices of ALL its winning triangles are requested up
-        // front (one round trip), so that an iteration below asks for its records AND its colours together: five dependent
-        // round trips per item instead of eight -- the resolve is bound by their latency, not by the texture unit's rate.
+        // A lane's pixels are p = tid + k * 512, k < 8, two per iteration. The corner indices of an iteration's winning
+        // triangles are requested one iteration ahead, so that an iteration asks for its corners, record AND colours together:
+        // five dependent round trips per item instead of eight (the resolve is bound by their latency, not by the texture
+        // unit's rate) -- on six registers; all eight pixels' indices up front (round 2) cost twenty-four.
         constexpr int kPixPerLane = kTile * kTile / kRasterThreads;
-        int3u corners[kPixPerLane];
-        if (MODE == 0) {
+        auto corners_of = [&](int it, int k) {
+            const int p = tid + (it * NP + k) * kRasterThreads;
+            const int py = p >> edge_shift, px = p & (edge - 1);
+            const unsigned lo = (p < npix && px < tw) ? kw[2 * (py * kTile + px)] : kNoTri;
+            return *reinterpret_cast<const int3u*>(a.m.tri + 3 * (size_t)(lo != kNoTri ? 0xFFFFFFFEu - lo : 0u));
+        };
+        int3u ahead[NP];
 #pragma unroll
-            for (int k = 0; k < kPixPerLane; ++k) {
-                const int p = tid + k * kRasterThreads;
-                const int py = p >> edge_shift, px = p & (edge - 1);
-                const unsigned lo = (p < npix && px < tw) ? kw[2 * (py * kTile + px)] : kNoTri;
-                corners[k] = *reinterpret_cast<const int3u*>(a.m.tri + 3 * (size_t)(lo != kNoTri ? 0xFFFFFFFEu - lo : 0u));
-            }
-        }
+        for (int k = 0; k < NP; ++k) ahead[k] = corners_of(0, k);
 #pragma unroll
         for (int it = 0; it < kPixPerLane / NP; ++it) {
             const int p0 = tid + it * NP * kRasterThreads;
             if (p0 >= npix) break;
             if (it == 1) fetch_next_entry();
+            int3u corners[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                corners[k] = ahead[k];
+                if (it + 1 < kPixPerLane / NP) ahead[k] = corners_of(it + 1, k);
+            }
             int lx[NP], ly[NP];
             unsigned f[NP];
             bool hit[NP];
@@ -1137,18 +1174,20 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
                 f[k] = hit[k] ? 0xFFFFFFFEu - lo : 0u;
             }
             if (!(hit[0] || hit[1])) continue;
-            float4 r0[NP], r1[NP];
-            float z1[NP], z2[NP];
+            float3u c0[NP], c1[NP], c2[NP];
+            float inv[NP];
             int i0[NP], i1[NP], i2[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                const float4* rp = rec_b + (size_t)f[k] * kRecF4;
+                i0[k] = corners[k].x, i1[k] = corners[k].y, i2[k] = corners[k].z;
                 if (DAD3D_RK_ABLATE & 8) {
-                    r0[k] = make_float4(1.f, 2.f, 3.f, (float)f[k]), r1[k] = make_float4(4.f, 5.f, 0.01f, 0.5f), z1[k] = 0.25f, z2[k] = 0.75f;
+                    c0[k] = float3u{1.f, 2.f, 0.5f}, c1[k] = float3u{5.f, 7.f, 0.25f}, c2[k] = float3u{4.f, (float)f[k], 0.75f}, inv[k] = 0.01f;
                 } else {
-                    r0[k] = rp[0], r1[k] = rp[1], z1[k] = rp[2].x, z2[k] = rp[2].y;
+                    c0[k] = *reinterpret_cast<const float3u*>(vb + 3 * (size_t)i0[k]);
+                    c1[k] = *reinterpret_cast<const float3u*>(vb + 3 * (size_t)i1[k]);
+                    c2[k] = *reinterpret_cast<const float3u*>(vb + 3 * (size_t)i2[k]);
+                    inv[k] = rec_b[f[k]].x;
                 }
-                if (MODE == 0) i0[k] = corners[it * NP + k].x, i1[k] = corners[it * NP + k].y, i2[k] = corners[it * NP + k].z;
             }
             float col[NP][3 * CC];
             if (packed) {
@@ -1174,10 +1213,10 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
             float u[NP], v[NP], w0[NP], z[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                const TriSetup ts = setup_from_record(r0[k], r1[k]);
+                const TriSetup ts = setup_from_corners(c0[k].x, c0[k].y, c1[k].x, c1[k].y, c2[k].x, c2[k].y, inv[k]);
                 tri_uv(ts, (float)(tx0 + lx[k]), (float)(ty0 + ly[k]), u[k], v[k]);
                 w0[k] = 1.0f - u[k] - v[k];
-                z[k] = w0[k] * r1[k].w + v[k] * z1[k] + u[k] * z2[k];
+                z[k] = w0[k] * c0[k].z + v[k] * c1[k].z + u[k] * c2[k].z;
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
@@ -1253,14 +1292,17 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     }
     }  // part inside the image
     stamp(4);
-    if (a.trace && tid == 0) {
+    if (DAD3D_RASTER_TRACE && a.trace && tid == 0) {
         unsigned long long* tr = a.trace + (size_t)item * kRasterWaves * 16;
         tr[5] = qe.x, tr[6] = n_items, tr[7] = n_total;
     }
     fetch_next_entry();
     if (tid == 0) s_item = gridDim.x + claimed, s_qe = next_qe;
     __syncthreads();  // keys and slist are reused by the next item; s_item and s_qe are published
-    item = s_item, qe = s_qe;
+    // wave-uniform by construction: say so, so that everything derived from the item (rectangle, image pointers) lives
+    // in scalar registers -- as VGPR copies they pushed the walk into scratch
+    item = (unsigned)__builtin_amdgcn_readfirstlane((int)s_item);
+    qe = make_uint2((unsigned)__builtin_amdgcn_readfirstlane((int)s_qe.x), (unsigned)__builtin_amdgcn_readfirstlane((int)s_qe.y));
     }
 }
 
@@ -1359,7 +1401,7 @@ struct ScratchLayout {
     ScratchLayout(const MeshDev& m, int batch, int h, int w) {
         const size_t nt = m.ntri, nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
         rec = 0;
-        counts = align256(rec + batch * nt * kRecF4 * sizeof(float4));
+        counts = align256(rec + batch * nt * sizeof(float3u));
         qhdr = align256(counts + 2 * nlists * sizeof(unsigned));
         queue = align256(qhdr + 4 * sizeof(unsigned));
         lists = align256(queue + nlists * kMaxSubs * sizeof(uint2));
@@ -1412,7 +1454,7 @@ dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc_all, v
     }
     const ScratchLayout lay(m, batch, h, w);
     char* base = static_cast<char*>(scratch);
-    RasterScratch sc{reinterpret_cast<float4*>(base + lay.rec),    reinterpret_cast<unsigned*>(base + lay.counts),
+    RasterScratch sc{reinterpret_cast<float3u*>(base + lay.rec),   reinterpret_cast<unsigned*>(base + lay.counts),
                      reinterpret_cast<unsigned*>(base + lay.lists), reinterpret_cast<unsigned*>(base + lay.qhdr),
                      reinterpret_cast<uint2*>(base + lay.queue),    tiles_of(w), tiles_of(h)};
     const int ntiles = sc.tiles_x * sc.tiles_y;
@@ -1456,7 +1498,7 @@ dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc_all, v
         }
         DAD3D_HIP_TRY(hipGetLastError());
     }
-    RasterArgs a{m, sc, image, colors, depth, tri_buf, bary, trace, h, w, c, reverse};
+    RasterArgs a{m, sc, image, vertices, colors, depth, tri_buf, bary, trace, h, w, c, reverse};
     const int blocks = (int)std::min<size_t>(persistent_blocks[mode ? 1 : 0], nlists * kMaxSubs);
     if (mode == 0)
         hipLaunchKernelGGL(raster_kernel<0>, dim3(blocks), dim3(kRasterThreads), 0, s, a);
