@@ -59,6 +59,7 @@ BYTES_PER_IMAGE = 105_672  # params 1652 + verts3d 60276 + proj2d 40184 + landma
 RASTER_BYTES_PER_IMAGE = 513_768  # rasterize; + 120 552 for the normals
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+REWARM_STEPS = int(os.environ.get("DAD3D_BENCH_REWARM", "8"))  # untimed steps between the opening barrier and the opening synchronize
 GOLDEN_SEED = 102  # tests/golden/decode_golden.npz "b64": rank 0 / stream 0 decodes exactly these rows
 
 
@@ -76,7 +77,7 @@ def cpu_baseline(model, lmk_idx, budget_s: float = 15.0):
     ncpu = os.cpu_count() or 1
     params = torch.from_numpy(synthetic.synthetic_params(256, seed=4242))
     tried = {}
-    candidates = [t for t in (1, 8, 32) if t <= ncpu] or [1]
+    candidates = sorted({t for t in (1, 8, 32, ncpu) if t <= ncpu}) or [1]  # os.cpu_count() threads as well
     with torch.no_grad():
         for threads in candidates:
             torch.set_num_threads(threads)
@@ -125,7 +126,7 @@ def pmc_json(name, key):
     collected in separate runs, KB units, FETCH doubled per MI355X_MICROARCH.md; SQ_VALU_MFMA_BUSY_CYCLES). PMC cannot be
     collected inside this process: these are CONSTANTS READ FROM COMMITTED FILES (the file is named next to them), null when
     absent."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
                 return json.load(f)[key], f"profiles/{rnd}_{name}.json"
@@ -230,6 +231,63 @@ def _stage_gathers_through_the_host(dist):
     dist._dad3d_shared_gpu = True
 
 
+def make_direct_gather(dist):
+    """The RCCL communicator for the job's one collective, created before anything is timed; None without a process group or
+    under the shared-GPU test hook (gloo)."""
+    if dist is None or getattr(dist, "_dad3d_shared_gpu", False) or dist.get_backend() != "nccl":
+        return None
+    from dad_3dheads_amd.rccl import RcclAllGather
+
+    return RcclAllGather()
+
+
+def time_gather(gather, dev, n: int = 20) -> float:
+    """Device time of ONE final gather in microseconds: events around n back-to-back gathers on the stream they run on
+    (after the timed region; its own figure so that a short scaling run can be read)."""
+    s = gather()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(n):
+        s = gather()
+    e1.record(s)
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def observed_shader_clock_mhz(step, dev):
+    """Shader clock under THIS load: rocm-smi's current sclk sampled while the step is issued back to back for ~0.2 s
+    (the spec peak in `roofline.peak` assumes 2400 MHz). None when rocm-smi is not there or prints nothing usable."""
+    import re
+    import subprocess
+    import threading
+
+    stop = threading.Event()
+
+    def spin():
+        while not stop.is_set():
+            for _ in range(64):
+                step()
+            torch.cuda.synchronize(dev)
+
+    th = threading.Thread(target=spin, daemon=True)
+    th.start()
+    vals = []
+    try:
+        t_end = time.perf_counter() + 2.0
+        while time.perf_counter() < t_end and len(vals) < 3:
+            r = subprocess.run(["rocm-smi", "--showclocks", "-d", str(dev.index or 0)], capture_output=True, text=True, timeout=10)
+            m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz", r.stdout, re.I)
+            if m:
+                vals.append(int(m.group(1)))
+    except Exception:
+        pass
+    finally:
+        stop.set()
+        th.join()
+    return max(vals) if vals else None
+
+
 def fence(dist, dev):
     if dist is not None:
         dist.barrier()
@@ -295,6 +353,7 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                               None, lmk_px.data_ptr(), streams[i].cuda_stream)})
     gathered = torch.empty((world * BATCH, N_LMK, 2), dtype=torch.int32, device=dev) if dist is not None else None
     decode = lib.dad3d_flame_decode
+    direct = make_direct_gather(dist)  # RCCL's C API on the launch stream (rccl.py); None under the shared-GPU test hook
     torch.cuda.synchronize(dev)
 
     def step(k):
@@ -302,9 +361,14 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         if st:
             _lib.check(st)
 
-    def gather_last(k_last):  # the job's one collective: landmarks of the last step, after that step's stream
-        torch.cuda.current_stream(dev).wait_stream(streams[k_last % n_streams])
+    def gather_last(k_last):  # the job's one collective: landmarks of the last step, ON that step's stream
+        s_last = streams[k_last % n_streams]
+        if direct is not None:
+            direct.all_gather(gathered, sets[k_last % n_streams]["lmk_px"], stream=s_last.cuda_stream)
+            return s_last
+        torch.cuda.current_stream(dev).wait_stream(s_last)
         dist.all_gather_into_tensor(gathered, sets[k_last % n_streams]["lmk_px"])
+        return torch.cuda.current_stream(dev)
 
     prewarm_ms = prewarm(step, args.prewarm_ms, dev)
     for k in range(args.warmup):
@@ -316,6 +380,12 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
     tot, cnt = C.c_double(), C.c_int()
     region0, region1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence(dist, dev)
+    if dist is not None and REWARM_STEPS:
+        # the barrier parks this rank's GPU for as long as the slowest rank needs (an idle millisecond drops the shader clock):
+        # a few untimed steps behind it, then the synchronize that opens the timed region (disclosed in config.rewarm_steps)
+        for k in range(REWARM_STEPS):
+            step(k)
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     if n_streams == 1:  # two hipEvents on the launch stream bracket the K launches of the timed region itself
         region0.record(streams[0])
@@ -324,13 +394,22 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         step(k)
     if n_streams == 1:
         _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
+    gather_host_us = gather_region_us = None
     if dist is not None:
-        gather_last(args.steps - 1)
-        region1.record(torch.cuda.current_stream(dev))  # behind the collective: the region's device time, host latency aside
+        pre_gather = torch.cuda.Event(enable_timing=True)
+        if n_streams == 1:
+            pre_gather.record(streams[0])
+        th0 = time.perf_counter()
+        s_gather = gather_last(args.steps - 1)
+        gather_host_us = (time.perf_counter() - th0) * 1e6
+        region1.record(s_gather)  # behind the collective: the region's device time, host latency aside
     fence(dist, dev)
     wall = max_over_ranks(dist, dev, time.perf_counter() - t0)
+    gather_us = time_gather(lambda: gather_last(args.steps - 1), dev) if dist is not None else None
     # Under a process group the job's device time is [first launch .. end of the all-gather] on this rank, MAX over ranks
     region_s = max_over_ranks(dist, dev, region0.elapsed_time(region1) * 1e-3) if (dist is not None and n_streams == 1) else None
+    if dist is not None and n_streams == 1:
+        gather_region_us = pre_gather.elapsed_time(region1) * 1e3  # the gather as it sat in the timed region (queued behind K launches)
 
     # dominant-kernel duration = hipEvent time of the K back-to-back launches / K (one kernel per step). With one
     # stream the events bracketed the timed region; with several, kernels of different streams overlap and a launch's
@@ -343,6 +422,7 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                 _lib.check(st)
         _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     kern_s = tot.value / max(cnt.value, 1) * 1e-3
+    clock_mhz = observed_shader_clock_mhz(lambda: step(0), dev) if rank == 0 else None
     events_s = max_over_ranks(dist, dev, tot.value * 1e-3)  # this rank's K launches on its stream, MAX over ranks
 
     timeouts = C.c_uint()
@@ -397,6 +477,12 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
             "outputs_verified": bool(check.get("ok")) and ok_gather if check and check.get("checked") else None,
             "verification": check,
             "handoff_timeouts": int(timeouts.value),
+            "gather_us": gather_us,
+            "gather_in_region_us": gather_region_us,
+            "gather_host_call_us": gather_host_us,
+            "rewarm_steps": REWARM_STEPS if dist is not None else 0,
+            "gather_via": None if dist is None else ("ncclAllGather on the launch stream (dad_3dheads_amd/rccl.py)" if direct is not None
+                                                    else "torch.distributed.all_gather_into_tensor"),
         },
         "roofline": {
             "kernel": "flame_decode_kernel<26,true,true> (pose role + decode role, one launch per step); duration = "
@@ -411,6 +497,8 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
             "mfma_busy_pmc": mfma_busy,
             "mfma_busy_source": mfma_src and mfma_src + " (committed PMC pass, NOT measured in this run)",
             "kernel_us": kern_s * 1e6,
+            "shader_clock_mhz": clock_mhz,
+            "frac_at_observed_clock": (flops / kern_s / 1e12 / (PEAK_FP32_MFMA_TFLOPS * clock_mhz / 2400.0)) if clock_mhz else None,
             "algorithmic_flop_per_launch": flops,
             "algorithmic_bytes_per_launch": alg_bytes,
             "hbm_equiv_GBps": alg_bytes / kern_s / 1e9,
@@ -432,13 +520,18 @@ def run_render(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
     faces = static["faces"]
     mesh = Mesh(faces, N_VERTS, device=dev.index)
     renderer = ShardedRenderer(hm, mesh)
+    direct = make_direct_gather(dist)
     params = torch.from_numpy(synthetic.synthetic_params(BATCH, seed=GOLDEN_SEED + rank)).to(dev)
     gathered = torch.empty((world * BATCH, 256, 256, 3), dtype=torch.uint8, device=dev) if dist is not None else None
     torch.cuda.synchronize(dev)
     step = lambda k: renderer.render_local(params)  # noqa: E731
 
-    def gather_last():
-        dist.all_gather_into_tensor(gathered, renderer._img)  # the images the last step rendered (same stream: ordered)
+    def gather_last():  # the images the last step rendered (same stream: ordered)
+        if direct is not None:
+            direct.all_gather(gathered, renderer._img)
+        else:
+            dist.all_gather_into_tensor(gathered, renderer._img)
+        return torch.cuda.current_stream(dev)
 
     prewarm_ms = prewarm(step, args.prewarm_ms, dev)
     for k in range(args.warmup):
@@ -458,6 +551,7 @@ def run_render(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
     fence(dist, dev)
     wall = max_over_ranks(dist, dev, time.perf_counter() - t0)
     ev_s = max_over_ranks(dist, dev, e0.elapsed_time(e1) * 1e-3)
+    gather_us = time_gather(gather_last, dev, n=5) if dist is not None else None
     steps_s = e0.elapsed_time(e_steps) * 1e-3  # this rank's K steps alone: the per-step duration behind `roofline`
     if rank != 0:
         return None
@@ -477,7 +571,7 @@ def run_render(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                                "one all-gather of the uint8 images ends the job",
                    "batch_per_gpu": BATCH, "global_batch": world * BATCH,
                    "parallelism": f"image-sharded x{world}, one final RCCL all-gather of [64,256,256,3] uint8 per rank",
-                   "prewarm_ms": prewarm_ms, "images_with_coverage": covered, "gather_verified": ok_gather,
+                   "prewarm_ms": prewarm_ms, "images_with_coverage": covered, "gather_verified": ok_gather, "gather_us": gather_us,
                    "value_from": "device events around the K timed steps" + (" AND the final all-gather (MAX over ranks)" if dist is not None else "")},
         "roofline": {"kernel": "decode + tri_geometry(+normals+light) + raster_kernel, three launches", "bound": "hbm",
                      "achieved": alg / (steps_s / args.steps) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -1,0 +1,101 @@
+"""RCCL called directly (ctypes on the librccl.so PyTorch-ROCm ships): the job's ONE collective on the launch stream.
+
+`torch.distributed.all_gather_into_tensor` on the "nccl" backend runs the collective on the process group's own stream:
+an event record + stream wait in front, another behind, per call. For a job whose whole device time is a few hundred
+microseconds (20 decode steps of 13 us) that plumbing was most of the timed region: ~180 us for a 228 KB gather in a
+world of one. Here the communicator is created up front (`ncclCommInitRank`, its
+unique id distributed through the existing torch.distributed group, whatever its backend) and `ncclAllGather` is queued on
+the stream the decode launches use -- no second stream, no events, capturable into a hipGraph with the launches.
+
+SURVEY section 8(e): the path shards by images and this all-gather is its only exchange; the reference has no counterpart
+(its only parallel entry is Lightning DDP, `model_training/train/flame_lightning_model.py:182-186`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_NCCL_CHAR = 0  # ncclInt8 / ncclChar
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_ubyte * 128)]  # not c_char: ctypes hands c_char arrays back as NUL-terminated bytes
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.isfile(path):
+            raise RuntimeError(f"librccl.so not found next to torch ({path}): the direct RCCL path needs PyTorch-ROCm")
+        lib = C.CDLL(path)
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _check(lib, status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {lib.ncclGetErrorString(status).decode()} ({status})")
+
+
+class RcclAllGather:
+    """One RCCL communicator over the ranks of `group` (default: the world), one device per rank (the current one)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("RcclAllGather needs an initialised torch.distributed group to hand out the unique id")
+        if not torch.cuda.is_available():
+            raise RuntimeError("RcclAllGather needs a GPU")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool's host driver
+        self.lib = _load()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(self.lib, self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        if not isinstance(box[0], bytes) or len(box[0]) != 128:
+            raise RuntimeError("RcclAllGather: the unique id did not arrive")
+        C.memmove(C.byref(uid), box[0], 128)
+        self.comm = C.c_void_p()
+        _check(self.lib, self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+        """out[r * n : (r + 1) * n] = rank r's `inp` (n = inp.numel(), any dtype: moved as bytes), queued on `stream`
+        (a raw hipStream_t; default: torch's current stream). Stream-ordered, no host synchronisation."""
+        if not (out.is_cuda and inp.is_cuda and out.is_contiguous() and inp.is_contiguous()):
+            raise ValueError("all_gather: contiguous device tensors only")
+        nbytes = inp.numel() * inp.element_size()
+        if out.dtype != inp.dtype or out.numel() * out.element_size() != self.world * nbytes:
+            raise ValueError("all_gather: `out` must hold world x `inp` of the same dtype")
+        if stream is None:
+            stream = torch.cuda.current_stream(inp.device).cuda_stream
+        _check(self.lib, self.lib.ncclAllGather(inp.data_ptr(), out.data_ptr(), nbytes, _NCCL_CHAR, self.comm, C.c_void_p(stream)),
+               "ncclAllGather")
+        return out
+
+    def destroy(self) -> None:
+        if getattr(self, "comm", None) is not None and self.comm.value:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -28,9 +28,11 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None, direct=None) -> torch.Tensor:
     """All-gather row-sharded `local` ([n_r, ...], n_r = this rank's shard of n_total rows) into the full
-    `[n_total, ...]` tensor on every rank. One collective; works for any dtype the backend supports."""
+    `[n_total, ...]` tensor on every rank. One collective; works for any dtype the backend supports.
+    `direct`: an `rccl.RcclAllGather` over the same ranks -- the collective is then queued on torch's current stream
+    through RCCL's C API instead of the process group's own stream (no event hops; see rccl.py)."""
     if not dist.is_available() or not dist.is_initialized():
         if local.shape[0] != n_total:
             raise ValueError("single process: local must already hold every row")
@@ -47,7 +49,10 @@ def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessG
         padded = local.new_zeros((width,) + tuple(local.shape[1:]))
         padded[: local.shape[0]] = local
     out = local.new_empty((world * width,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if direct is not None:
+        direct.all_gather(out, padded.contiguous())
+    else:
+        dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
     if all(s == width for s in sizes):
         return out
     return torch.cat([out[r * width : r * width + sizes[r]] for r in range(world)], dim=0)
@@ -56,9 +61,16 @@ def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessG
 class ShardedLandmarkDecoder:
     """Decode the rows this rank owns and gather the landmarks of the whole batch (BASELINE config 4)."""
 
-    def __init__(self, head_mesh, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, head_mesh, group: Optional[dist.ProcessGroup] = None, direct_rccl: bool = False):
+        """direct_rccl: gather through `rccl.RcclAllGather` (communicator created here, collective on the launch stream)
+        instead of `torch.distributed.all_gather_into_tensor`; needs the "nccl" backend's hardware, i.e. one GPU per rank."""
         self.head_mesh = head_mesh
         self.group = group
+        self.direct = None
+        if direct_rccl and dist.is_available() and dist.is_initialized():
+            from .rccl import RcclAllGather
+
+            self.direct = RcclAllGather(group)
 
     def __call__(self, params_global: torch.Tensor) -> torch.Tensor:
         """params_global [B,P] (every rank passes the same host/device tensor or just needs its own rows valid)
@@ -76,7 +88,7 @@ class ShardedLandmarkDecoder:
                                        mutate=False)["lmk_px"]
         else:
             px = torch.empty((0, self.head_mesh.flame.n_landmarks, 2), dtype=torch.int32, device=dev)
-        return gather_rows(px, n, self.group)
+        return gather_rows(px, n, self.group, self.direct)
 
 
 class ShardedRenderer:
@@ -85,8 +97,14 @@ class ShardedRenderer:
     batch -- fused decode (3-component projection, z flipped like `demo_utils.get_vertices_for_render`), the raster's
     geometry kernel (vertex normals + Phong light + triangle records), the tile kernel -- and no host copy."""
 
-    def __init__(self, head_mesh, mesh, group: Optional[dist.ProcessGroup] = None, image_size: int = 256, **light):
+    def __init__(self, head_mesh, mesh, group: Optional[dist.ProcessGroup] = None, image_size: int = 256,
+                 direct_rccl: bool = False, **light):
         self.head_mesh, self.mesh, self.group = head_mesh, mesh, group
+        self.direct = None
+        if direct_rccl and dist.is_available() and dist.is_initialized():
+            from .rccl import RcclAllGather
+
+            self.direct = RcclAllGather(group)
         self.image_size = int(image_size)
         self.light = light
         self._dec, self._img, self._light_buf = {}, None, None
@@ -111,4 +129,7 @@ class ShardedRenderer:
         lo, hi = shard_range(n, rank, world)
         dev = self.head_mesh.flame.torch_device
         mine = params_global[lo:hi].to(dev, torch.float32).contiguous()
-        return gather_rows(self.render_local(mine), n, self.group)
+        img = self.render_local(mine)
+        if not (dist.is_available() and dist.is_initialized()):
+            return img.clone()  # render_local's buffer is reused by the next call; the gathered tensor of the other path is fresh
+        return gather_rows(img, n, self.group, self.direct)

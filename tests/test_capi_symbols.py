@@ -67,3 +67,13 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, fn)
                 assert "oracle/" not in src or fn.endswith(".md"), os.path.join(dirpath, fn)
+
+
+def test_rccl_binding_resolves_its_entry_points():
+    """dad_3dheads_amd/rccl.py binds RCCL's C API by name from the librccl.so PyTorch-ROCm ships (no GPU needed to look)."""
+    from dad_3dheads_amd import rccl
+
+    lib = rccl._load()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString"):
+        assert hasattr(lib, name), name
+    assert ctypes.sizeof(rccl._UniqueId) == 128

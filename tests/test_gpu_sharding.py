@@ -43,6 +43,36 @@ def head_mesh(static, flame_model):
     return HeadMesh(flame_model=flame_model, landmarks=landmarks.canonical("445", static), static=static, device=0)
 
 
+def test_direct_rccl_all_gather_on_the_launch_stream(nccl_world1, head_mesh):
+    """rccl.RcclAllGather: communicator from ncclCommInitRank (unique id through the torch group), ncclAllGather queued on a
+    side stream behind a decode launched there -- the gathered landmarks are what that launch wrote, and the sharded decoder
+    gives the same tensor through either gather."""
+    from dad_3dheads_amd import sharding, synthetic
+    from dad_3dheads_amd.rccl import RcclAllGather
+
+    rg = RcclAllGather()
+    assert rg.world == 1 and rg.rank == 0
+    side = torch.cuda.Stream()
+    params = torch.from_numpy(synthetic.synthetic_params(64, seed=77)).cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        px = head_mesh.decode(params, verts3d=False, proj=False, landmarks=False, landmarks_px=True, mutate=False)["lmk_px"]
+        out = torch.empty_like(px)
+        rg.all_gather(out, px, stream=side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(out, px) and int(px.abs().max()) > 0
+    for dtype in (torch.uint8, torch.float32):  # any dtype: moved as bytes
+        x = (torch.arange(3 * 5 * 7, device="cuda") % 251).to(dtype).reshape(3, 5, 7)
+        assert torch.equal(rg.all_gather(torch.empty_like(x), x), x)
+    with pytest.raises(ValueError):
+        rg.all_gather(torch.empty(5, device="cuda"), torch.empty(6, device="cuda"))
+    a = sharding.ShardedLandmarkDecoder(head_mesh)(params)
+    b = sharding.ShardedLandmarkDecoder(head_mesh, direct_rccl=True)(params)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    rg.destroy()
+
+
 def test_sharded_landmark_decoder_under_rccl_matches_oracle(nccl_world1, head_mesh, flame_consts, static):
     """BASELINE config 4's per-rank code path: shard -> fused decode -> ONE all_gather_into_tensor on RCCL."""
     from dad_3dheads_amd import sharding, synthetic
