@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DAD3D_LIB_PATH") or os.path.join(_HERE, "libdad3d_hip.so")  # override: diagnostics builds
 
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = range(5)
-ZERO_ROTATION, TO_2D, MUTATE_PARAMS, FLIP_Z = 0x1, 0x2, 0x4, 0x8
+ZERO_ROTATION, TO_2D, MUTATE_PARAMS, FLIP_Z, COMPAT_CROSS_B3 = 0x1, 0x2, 0x4, 0x8, 0x10
 NORMAL_ACCUMULATE = 0x1
 
 

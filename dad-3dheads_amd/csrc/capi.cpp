@@ -209,6 +209,24 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
         return m->v_template[(size_t)v * 3 + comp];  // k == NB + n_pose_feats: the row multiplied by 1
     };
     std::vector<float> bpack((size_t)h->n_tiles * h->kgroups * 4 * 64 * 4, 0.0f);
+#if defined(DAD3D_MFMA32) && DAD3D_MFMA32
+    // 32x32x2 tiling of flame_decode.hip: [tile][group][column half wc][lane][8]: lane (hh = lane >> 5, n = lane & 31) supplies
+    // basis rows k = 16 g + 8 hh + i, i = 0..7, of column 32 wc + n
+    for (int t = 0; t < h->n_tiles; ++t)
+        for (int g = 0; g < h->kgroups; ++g)
+            for (int wc = 0; wc < 2; ++wc)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int col = wc * 32 + (lane & 31);
+                    const int v = t * kTileVerts + col / 3, comp = col % 3;
+                    if (col >= kTileVerts * 3 || v >= V) continue;
+                    float* dst = &bpack[((((size_t)t * h->kgroups + g) * 2 + wc) * 64 + lane) * 8];
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = 16 * g + 8 * (lane >> 5) + i;
+                        if (k < k_used) dst[i] = basis(k, v, comp);
+                    }
+                }
+    if (false)
+#endif
     for (int t = 0; t < h->n_tiles; ++t)
         for (int g = 0; g < h->kgroups; ++g)
             for (int w = 0; w < 4; ++w)

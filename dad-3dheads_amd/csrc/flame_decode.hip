@@ -32,10 +32,14 @@
 #ifndef DAD3D_ABLATE  // diagnostics builds only (tools/ablate.sh); 0 in the product
 #define DAD3D_ABLATE 0
 #endif
+#ifndef DAD3D_MFMA32  // 1: the four multiplying waves tile the 64 x 64 block 2 x 2 with v_mfma_f32_32x32x2_f32 (half the MFMA
+#define DAD3D_MFMA32 0  // issues and half the A-fragment reads per MAC); needs the matching basis pack of capi.cpp
+#endif
 
 namespace dad3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B load from a 4-byte aligned row
@@ -169,10 +173,41 @@ __device__ __forceinline__ ImageScalars load_scalars(const float* p, const Param
     return s;
 }
 
+// DAD3D_COMPAT_CROSS_B3, batch == 3 only: rot_mat_from_6dof as the reference evaluates it for three rows -- torch.cross without
+// `dim` (model/utils.py:98-99) runs over the BATCH axis of the [3,3] operands: out[i][c] = x[i+1][c] y[i+2][c] - x[i+2][c] y[i+1][c]
+// (indices mod 3). F.normalize stays per row. Every wave recomputes the three images' b1 and b3 (a few dozen flops).
+__device__ __forceinline__ void rot6_batch3_compat(const DecodeArgs& a, int me, float b1o[3], float b2o[3], float b3o[3]) {
+    float b1[3][3], vy[3][3], b3[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float* p = a.params + (size_t)i * a.lay.n_params + a.lay.rot_off;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b1[i][c] = p[c], vy[i][c] = p[3 + c];
+        normalize3(b1[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b3[i][c] = b1[(i + 1) % 3][c] * vy[(i + 2) % 3][c] - b1[(i + 2) % 3][c] * vy[(i + 1) % 3][c];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) normalize3(b3[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i == me) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                b1o[c] = b1[i][c];
+                b3o[c] = b3[i][c];
+                b2o[c] = -(b1[(i + 1) % 3][c] * b3[(i + 2) % 3][c] - b1[(i + 2) % 3][c] * b3[(i + 1) % 3][c]);
+            }
+        }
+}
+
 // joints + pose inputs -> the block, in registers (a few hundred flops; every lane computes it redundantly)
 template <bool JAW_ONLY>
 __device__ __forceinline__ void constants_from_joints(const DecodeArgs& a, const float J[kNumJoints][3],
-                                                      const ImageScalars& in, float out[kImgConsts]) {
+                                                      const ImageScalars& in, float out[kImgConsts], int img = -1) {
     float WR[kNumJoints][9], Wt[kNumJoints][3];
     if (JAW_ONLY) {
         // world_j = world_parent . [R_j | J_j - J_parent] with R_j = I except the jaw
@@ -242,8 +277,9 @@ __device__ __forceinline__ void constants_from_joints(const DecodeArgs& a, const
     normalize3(b1);
     float b3[3] = {b1[1] * vy[2] - b1[2] * vy[1], b1[2] * vy[0] - b1[0] * vy[2], b1[0] * vy[1] - b1[1] * vy[0]};
     normalize3(b3);
-    const float b2[3] = {-(b1[1] * b3[2] - b1[2] * b3[1]), -(b1[2] * b3[0] - b1[0] * b3[2]),
-                         -(b1[0] * b3[1] - b1[1] * b3[0])};
+    float b2[3] = {-(b1[1] * b3[2] - b1[2] * b3[1]), -(b1[2] * b3[0] - b1[0] * b3[2]),
+                   -(b1[0] * b3[1] - b1[1] * b3[0])};
+    if ((a.flags & DAD3D_COMPAT_CROSS_B3) && a.batch == 3 && img >= 0) rot6_batch3_compat(a, img, b1, b2, b3);
     // A_j = world_j - [0 | world_j . J_j]
 #pragma unroll
     for (int j = 0; j < kNumJoints; ++j) {
@@ -300,7 +336,7 @@ __device__ __forceinline__ float4 lane_betas(const DecodeArgs& a, const float* p
 // Stand-alone form (used only when a decode workgroup gave up waiting for the pose role): one wave computes
 // the block of one image straight from global memory and lane 0 writes it to `dst` (LDS).
 template <bool JAW_ONLY, bool CONTIG>
-__device__ void image_constants(const DecodeArgs& a, const float* p, float* dst, int lane) {
+__device__ void image_constants(const DecodeArgs& a, const float* p, float* dst, int lane, int img) {
     const ImageScalars in = load_scalars(p, a.lay);
     float jacc[3 * kNumJoints];
 #pragma unroll
@@ -321,7 +357,7 @@ __device__ void image_constants(const DecodeArgs& a, const float* p, float* dst,
 #pragma unroll
     for (int o = 0; o < 3 * kNumJoints; ++o) J[o / 3][o % 3] = a.j0[o] + wave_sum(jacc[o]);
     float out[kImgConsts];
-    constants_from_joints<JAW_ONLY>(a, J, in, out);
+    constants_from_joints<JAW_ONLY>(a, J, in, out, img);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < kImgConsts; ++i) dst[i] = out[i];
@@ -332,7 +368,9 @@ __device__ void image_constants(const DecodeArgs& a, const float* p, float* dst,
 template <int KG>
 struct DecodeLds {
     static constexpr int K = KG * 16;
-    static constexpr int LD = (KG == 26) ? 424 : 456;  // row stride: ds_read_b128 of the A operand conflict-free
+    // row stride: ds_read_b128 of the A operand conflict-free (16x16x4: lanes (row i, k 4q); 32x32x2: lanes (row i, k 8h):
+    // the 16 lanes the LDS serves together hold 16 different rows, so LD / 4 must be odd)
+    static constexpr int LD = DAD3D_MFMA32 ? ((KG == 26) ? 420 : 452) : ((KG == 26) ? 424 : 456);
     static constexpr int a_off = 0;                    // [64 images][LD]
     static constexpr int imgc_off = kBlockImages * LD;                   // [64][kImgConsts]
     static constexpr int vc_off = imgc_off + kBlockImages * kImgConsts;  // [21][8] skinning weights
@@ -428,7 +466,7 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
     }
     if (trace && lane == 0) trace[5] = __builtin_readcyclecounter();
     if (rep == 1 && trace && lane == 0) trace[9] = __builtin_readcyclecounter();
-    constants_from_joints<JAW_ONLY>(a, J, in, out);
+    constants_from_joints<JAW_ONLY>(a, J, in, out, b);
     if (rep == 1 && trace && lane == 0) trace[7] = __builtin_readcyclecounter();
     }
     if (trace && lane == 0) trace[1] = __builtin_readcyclecounter();
@@ -561,7 +599,54 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         if (lane == 0) __hip_atomic_fetch_add(part_ready + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    if (wave < 4) {
+    if (wave < 4 && DAD3D_MFMA32 && RB == 4) {
+        // =============================== mma waves, 32x32x2 tiling ==============================
+        // wave = (row half wr, column half wc): images [32 wr, 32 wr + 32) x columns [32 wc, 32 wc + 32), ONE 32x32
+        // accumulator. MFMA step (G, s), s = 0..7: lane (h = lane >> 5, i = lane & 31) contributes basis row
+        // k = 16 G + 8 h + s: its A operands of a group are the two float4 at a_lds[32 wr + i][16 G + 8 h], its B operands
+        // the two float4 the host packed for (G, wc, lane). 208 MFMAs of 64 cycles instead of 416 of 32, two ds_read_b128
+        // per eight MFMAs instead of four per sixteen.
+        const int wc = wave & 1, wr = wave >> 1;
+        const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 2 + wc) * 128 + lane * 2;
+        constexpr int kBAhead = 6;
+        float4 bq0[KG], bq1[KG];
+#pragma unroll
+        for (int G = 0; G < kBAhead && G < KG; ++G) bq0[G] = bsrc[(size_t)G * 256], bq1[G] = bsrc[(size_t)G * 256 + 1];
+        f32x16 acc32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[r] = 0.0f;
+        const float* afrag = a_lds + (32 * wr + (lane & 31)) * LD + 8 * (lane >> 5);
+        float4 af0, af1, an0 = {}, an1 = {};
+        stamp(1);
+        wait_part(0);
+        stamp(2);
+        af0 = *reinterpret_cast<const float4*>(afrag), af1 = *reinterpret_cast<const float4*>(afrag + 4);
+#pragma unroll
+        for (int G = 0; G < KG; ++G) {
+            if (G + 1 == PT::begin(1) || G + 1 == PT::begin(2)) wait_part(G + 1 == PT::begin(1) ? 1 : 2);
+            if (G + 1 < KG) {
+                an0 = *reinterpret_cast<const float4*>(afrag + 16 * (G + 1));
+                an1 = *reinterpret_cast<const float4*>(afrag + 16 * (G + 1) + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sst = 0; sst < 8; ++sst) {
+                const float4 aq = sst < 4 ? af0 : af1, bb4 = sst < 4 ? bq0[G] : bq1[G];
+                const int e = sst & 3;
+                const float av = e == 0 ? aq.x : e == 1 ? aq.y : e == 2 ? aq.z : aq.w;
+                const float bv = e == 0 ? bb4.x : e == 1 ? bb4.y : e == 2 ? bb4.z : bb4.w;
+                acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc32, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            af0 = an0, af1 = an1;
+            if (G + kBAhead < KG) bq0[G + kBAhead] = bsrc[(size_t)(G + kBAhead) * 256], bq1[G + kBAhead] = bsrc[(size_t)(G + kBAhead) * 256 + 1];
+        }
+        stamp(3);
+        // D layout of the 32x32 accumulator: register r of lane (h, i) = row 8 (r / 4) + 4 h + r % 4, column i
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            otile[(32 * wr + 8 * (r / 4) + 4 * (lane >> 5) + (r & 3)) * kOutStride + 32 * wc + (lane & 31)] = acc32[r];
+    } else if (wave < 4) {
         // =============================== mma waves ===============================================
         // acc[m] = images [16m,16m+16) x columns [16*wave,16*wave+16). MFMA step (G, s): lane group
         // q = lane>>4 contributes basis row k = 16G + 4q + s, so the A operand of lane (q, i) for s = 0..3 is
@@ -758,7 +843,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
             if (lane == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < 16; ++i) {
                 const int row = (wave - 4) * 16 + i;
-                if (img0 + row < a.batch) image_constants<JAW_ONLY, CONTIG>(a, a.params + (size_t)(img0 + row) * P, imgc + row * kImgConsts, lane);
+                if (img0 + row < a.batch) image_constants<JAW_ONLY, CONTIG>(a, a.params + (size_t)(img0 + row) * P, imgc + row * kImgConsts, lane, img0 + row);
             }
         }
     }

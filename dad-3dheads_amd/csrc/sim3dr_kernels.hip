@@ -731,9 +731,9 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
         box[k] = make_uint2(1u, 1u);  // empty
         if (fl >= tris_per_block || f >= m.ntri) continue;
         const int i0 = m.tri[3 * f], i1 = m.tri[3 * f + 1], i2 = m.tri[3 * f + 2];
-        const float x0 = coord(3 * i0), y0 = coord(3 * i0 + 1), z0 = coord(3 * i0 + 2);
-        const float x1 = coord(3 * i1), y1 = coord(3 * i1 + 1), z1 = coord(3 * i1 + 2);
-        const float x2 = coord(3 * i2), y2 = coord(3 * i2 + 1), z2 = coord(3 * i2 + 2);
+        const float x0 = coord(3 * i0), y0 = coord(3 * i0 + 1);  // the depths are read by the tile kernel, from the vertex array
+        const float x1 = coord(3 * i1), y1 = coord(3 * i1 + 1);
+        const float x2 = coord(3 * i2), y2 = coord(3 * i2 + 1);
         // bounding box exactly as rasterize_kernel.cpp:246-254
         int bx0 = max(f2i_x86(ceilf(std_min(x0, std_min(x1, x2)))), 0);
         int bx1 = min(f2i_x86(floorf(std_max(x0, std_max(x1, x2)))), w - 1);

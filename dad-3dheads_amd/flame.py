@@ -216,7 +216,9 @@ class FLAMELayer(torch.nn.Module):
                landmarks: bool = False, landmarks_px: bool = False, zero_rot: bool = False, flip_z: bool = False,
                mutate: bool = False, out: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
         """One fused launch producing any subset of the outputs; `params` must be a CUDA fp32 [B,P] tensor
-        on this layer's device (contiguous). Async on torch's current stream."""
+        on this layer's device (contiguous). Async on torch's current stream.
+        `self.compat_cross_b3` (default False): reproduce the reference's batch-of-exactly-three result, where
+        `torch.cross` without `dim` (model/utils.py:98-99) crosses over the batch axis (DAD3D_COMPAT_CROSS_B3)."""
         if params.ndim != 2:
             raise AssertionError("tensor_3dmm.ndim == 2 expected")  # flame.py:46
         if params.shape[1] != self.n_params:
@@ -247,7 +249,8 @@ class FLAMELayer(torch.nn.Module):
         p_lx = buf("lmk_xy", (b, self.n_landmarks, 2)).data_ptr() if landmarks else None
         p_lp = buf("lmk_px", (b, self.n_landmarks, 2), torch.int32).data_ptr() if landmarks_px else None
         flags = (_lib.ZERO_ROTATION if zero_rot else 0) | (_lib.TO_2D if to_2d else 0) | \
-            (_lib.MUTATE_PARAMS if mutate else 0) | (_lib.FLIP_Z if flip_z else 0)
+            (_lib.MUTATE_PARAMS if mutate else 0) | (_lib.FLIP_Z if flip_z else 0) | \
+            (_lib.COMPAT_CROSS_B3 if getattr(self, "compat_cross_b3", False) else 0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(self._lib.dad3d_flame_decode(self._handle, params.data_ptr(), b, flags, p_v, p_p, p_lx, p_lp, stream))
         return res

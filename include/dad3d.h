@@ -68,6 +68,11 @@ typedef struct dad3d_flame dad3d_flame; /* opaque: packed basis + scratch reside
 #define DAD3D_MUTATE_PARAMS 0x4u /* write translation z := 0 back into `params`, the side effect of
                                     HeadMesh.reprojected_vertices (head_mesh.py:41) */
 #define DAD3D_FLIP_Z 0x8u        /* negate proj z (inference/pncc_estimator.py:88), needs !TO_2D */
+#define DAD3D_COMPAT_CROSS_B3 0x10u /* opt-in bug compatibility: model_training/model/utils.py:98-99 calls torch.cross WITHOUT
+                                    `dim`; for a batch of EXACTLY three rows torch's legacy rule takes the first axis of size
+                                    3 -- the batch axis -- so the three images' 6-DoF rotations mix. With this flag a batch of
+                                    three reproduces that (every other batch size is unaffected); without it (default) every
+                                    image gets its own Gram-Schmidt rotation, as for any other batch size */
 
 /* Upload + repack the model for `device`. Replaces FLAMELayer.__init__ (flame.py:124-180) and
  * HeadMesh.__init__ (head_mesh.py:10-22). `image_size` is HeadMesh._image_size (256). */

@@ -264,7 +264,8 @@ def test_projection_oracle_matches_reference_goldens():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/dad_3dheads_benchmark"), reason="reference tree not present on this machine")
 @pytest.mark.parametrize("script,fixture", [("make_lmk68_fixture.py", "lmk68_embedding.npz"), ("make_projection_golden.py", "projection_golden.npz"),
-                                            ("make_loss_golden.py", "loss_golden.npz"), ("make_writers_golden.py", "writers_golden.npz")])
+                                            ("make_loss_golden.py", "loss_golden.npz"), ("make_writers_golden.py", "writers_golden.npz"),
+                                            ("make_decode_b3_golden.py", "decode_b3_golden.npz")])
 def test_committed_goldens_are_what_the_reference_produces_here(tmp_path, script, fixture):
     """Authoring container only: re-run the generator (the reference's own functions, imported from where they lie)
     and compare every array with the committed fixture."""
