@@ -1,0 +1,109 @@
+"""GPU: hypothesis-driven adversarial meshes for the z-buffer raster and the normals, bit-exact against the compiled reference
+(oracle/_ref/libsim3dr_ref.so when present, the C port otherwise).
+
+The cases aim at where a parallel restatement of Sim3DR/lib/rasterize_kernel.cpp:219-353 can go wrong while a head mesh never
+shows it: vertices exactly on pixel centres (the strict `> 0` interior test of _rasterize against the `>= 0` of
+_rasterize_triangles), zero-area and sliver triangles (inv = 0 or huge: NaN / inf barycentrics), exact depth ties between
+triangles that land in DIFFERENT 64 x 64 tiles and in split tiles (tie -> lowest triangle index), boxes that straddle tile
+borders and the image edge, triangles as large as the image next to hundreds of tiny ones (every area class of the lane
+allocation in one list), repeated indices, huge coordinates. Shrunk counter-examples, if any ever appear, belong in
+tests/golden/ (none so far)."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from dad_3dheads_amd.Sim3DR import Mesh
+
+pytestmark = pytest.mark.gpu
+
+PROFILES = ("pixel_centres", "slivers", "tie_planes", "tile_straddle", "mixed_sizes", "split_tile", "wild")
+
+
+def build_case(seed: int, profile: str):
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(40, 200)), int(rng.integers(40, 280))
+    if profile == "split_tile":
+        h, w = 128, 192
+    nver = int(rng.integers(6, 120))
+    ntri = int(rng.integers(4, 260))
+    v = np.empty((nver, 3), np.float32)
+    v[:, 0] = rng.uniform(-12, w + 12, nver)
+    v[:, 1] = rng.uniform(-12, h + 12, nver)
+    v[:, 2] = rng.uniform(-4, 4, nver)
+    t = rng.integers(0, nver, (ntri, 3)).astype(np.int32)
+    if profile == "pixel_centres":  # every vertex on a pixel centre, half-integer depths: edges run through pixel centres
+        v[:, :2] = np.round(v[:, :2])
+        v[:, 2] = np.round(v[:, 2] * 2) / 2
+    elif profile == "slivers":  # collinear and nearly collinear corners, repeated corners, tiny areas
+        base = rng.integers(0, nver, ntri)
+        d = rng.uniform(-30, 30, (ntri, 2)).astype(np.float32)
+        extra = nver + 2 * ntri
+        v2 = np.empty((extra, 3), np.float32)
+        v2[:nver] = v
+        for k in range(ntri):
+            a = v[base[k]]
+            e = float(rng.choice([0.0, 1e-6, 1e-4, 1e-2, 0.3]))
+            v2[nver + 2 * k] = [a[0] + d[k, 0], a[1] + d[k, 1], a[2] + 1]
+            v2[nver + 2 * k + 1] = [a[0] + 2 * d[k, 0] - e * d[k, 1], a[1] + 2 * d[k, 1] + e * d[k, 0], a[2] - 1]
+        t = np.stack([base, nver + 2 * np.arange(ntri), nver + 2 * np.arange(ntri) + 1], 1).astype(np.int32)
+        t[::7, 2] = t[::7, 1]  # a repeated corner: exactly zero area
+        v, nver = v2, extra
+    elif profile == "tie_planes":  # constant-depth planes: every overlap is an exact tie, decided by the triangle index
+        v[:, 2] = np.round(v[:, 2])
+        v[rng.integers(0, nver, nver // 2), 2] = 1.0
+    elif profile == "tile_straddle":  # corners hugging the 64-pixel tile borders and the image edge
+        snap = rng.choice([0.0, 63.0, 64.0, 127.0, 128.0, float(w - 1), float(w)], nver)
+        v[:, 0] = snap + rng.choice([-1.0, -0.5, -1e-3, 0.0, 1e-3, 0.5, 1.0], nver) + rng.uniform(-3, 3, nver) * (rng.random(nver) < 0.5)
+        snap = rng.choice([0.0, 63.0, 64.0, float(h - 1), float(h)], nver)
+        v[:, 1] = snap + rng.choice([-1.0, -0.5, 0.0, 0.5, 1.0], nver) + rng.uniform(-40, 40, nver) * (rng.random(nver) < 0.5)
+        v = v.astype(np.float32)
+    elif profile == "mixed_sizes":  # a few image-sized triangles among many small ones, equal depths between the two kinds
+        near = rng.integers(0, nver, ntri)
+        t = np.stack([near, (near + 1) % nver, (near + 2) % nver], 1).astype(np.int32)
+        order = np.argsort(v[:, 0] // 6 * 1000 + v[:, 1])
+        v = v[order]
+        big = np.array([[-50, -50, 0.5], [w + 60, -40, 0.5], [w / 2, h + 90, 0.5], [-30, h + 20, -0.5]], np.float32)
+        v = np.concatenate([v, big]).astype(np.float32)
+        t = np.concatenate([t, np.array([[nver, nver + 1, nver + 2], [nver + 3, nver + 1, nver + 2], [nver, nver + 2, nver + 3]], np.int32)])
+        v[: nver // 3, 2] = 0.5
+        nver += 4
+    elif profile == "split_tile":  # one tile far beyond the split threshold: 2x2 and 4x4 parts, lists re-classed per part
+        nver, ntri = 400, 900
+        v = np.empty((nver, 3), np.float32)
+        v[:, 0] = rng.uniform(60, 132, nver)
+        v[:, 1] = rng.uniform(-4, 70, nver)
+        v[:, 2] = np.round(rng.uniform(-3, 3, nver))
+        t = rng.integers(0, nver, (ntri, 3)).astype(np.int32)
+    elif profile == "wild":  # huge and non-finite-producing coordinates next to ordinary ones
+        v[rng.integers(0, nver, 3), 0] = rng.choice([1e7, -1e7, 3e38, -3e38, 65535.5])
+        v[rng.integers(0, nver, 2), 1] = rng.choice([1e7, -3e38])
+        v[rng.integers(0, nver, 2), 2] = rng.choice([3e38, -3e38, 1e-40])
+    c = int(rng.choice([1, 3, 3, 4]))
+    col = rng.uniform(-0.2, 1.2, (nver, c)).astype(np.float32)  # colours a little outside [0, 1]: the (uchar) cast wraps
+    bg = rng.integers(0, 255, (h, w, c)).astype(np.uint8)
+    return np.ascontiguousarray(v, np.float32), np.ascontiguousarray(t), col, bg, h, w, bool(rng.integers(0, 2))
+
+
+@settings(max_examples=42, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), profile=st.sampled_from(PROFILES))
+def test_raster_and_normals_fuzz_bit_exact(sim3dr_oracle, seed, profile):
+    v, t, col, bg, h, w, rev = build_case(seed, profile)
+    mesh = Mesh(t, v.shape[0], device=0)
+    dv = torch.from_numpy(v).cuda()[None]
+    img = torch.from_numpy(bg.copy()).cuda()[None].contiguous()
+    depth = torch.full((1, h, w), -1e8, device="cuda")
+    mesh.rasterize(dv, torch.from_numpy(col).cuda()[None], img, depth=depth, reverse=rev)
+    with np.errstate(all="ignore"):
+        ref_img, ref_depth = sim3dr_oracle.rasterize(v, t, col, bg=bg.copy(), reverse=rev, return_depth=True)
+        rd, rtb, rbw = sim3dr_oracle.rasterize_triangles(v, t, h, w)
+        ref_n = sim3dr_oracle.get_normal(v, t)
+    assert np.array_equal(img[0].cpu().numpy(), ref_img), (profile, seed)
+    assert np.array_equal(depth[0].cpu().numpy(), ref_depth, equal_nan=True), (profile, seed)
+    d, tb, bw = mesh.rasterize_triangles(dv, h, w)
+    won = rtb >= 0
+    assert np.array_equal(d[0].cpu().numpy(), rd, equal_nan=True), (profile, seed)
+    assert np.array_equal(tb[0].cpu().numpy()[won], rtb[won]), (profile, seed)
+    assert np.array_equal(bw[0].cpu().numpy()[won], rbw[won], equal_nan=True), (profile, seed)
+    assert np.array_equal(mesh.get_normal(dv)[0].cpu().numpy(), ref_n, equal_nan=True), (profile, seed)
