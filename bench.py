@@ -255,37 +255,28 @@ def time_gather(gather, dev, n: int = 20) -> float:
     return e0.elapsed_time(e1) / n * 1e3
 
 
-def observed_shader_clock_mhz(step, dev):
-    """Shader clock under THIS load: rocm-smi's current sclk sampled while the step is issued back to back for ~0.2 s
-    (the spec peak in `roofline.peak` assumes 2400 MHz). None when rocm-smi is not there or prints nothing usable."""
-    import re
-    import subprocess
-    import threading
+def observed_shader_clock_mhz(lib, handle, call, dev):
+    """Shader clock the decode kernel actually ran at: ONE extra launch after the timed region with the kernel's own phase
+    stamps switched on (dad3d_flame_debug_trace: s_memtime shader cycles and the 100 MHz wall clock at each wave's start and
+    end); clock = cycles / wall time, median over the decode workgroups' first waves. The roofline peak assumes 2400 MHz; rocm-smi
+    reports the DPM level (~2.39 GHz), not what a power-limited MFMA kernel sustains. None when the trace comes back empty."""
+    from dad_3dheads_amd import _lib
 
-    stop = threading.Event()
-
-    def spin():
-        while not stop.is_set():
-            for _ in range(64):
-                step()
-            torch.cuda.synchronize(dev)
-
-    th = threading.Thread(target=spin, daemon=True)
-    th.start()
-    vals = []
     try:
-        t_end = time.perf_counter() + 2.0
-        while time.perf_counter() < t_end and len(vals) < 3:
-            r = subprocess.run(["rocm-smi", "--showclocks", "-d", str(dev.index or 0)], capture_output=True, text=True, timeout=10)
-            m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz", r.stdout, re.I)
-            if m:
-                vals.append(int(m.group(1)))
+        n_rows = (240 * 8 + 16 * 4) * 32
+        trace = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+        for _ in range(50):  # clocks as in the timed region
+            lib.dad3d_flame_decode(*call)
+        _lib.check(lib.dad3d_flame_debug_trace(handle, trace.data_ptr()))
+        _lib.check(lib.dad3d_flame_decode(*call))
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.dad3d_flame_debug_trace(handle, None))
+        t = trace.cpu().numpy().astype(np.float64)[: 240 * 8 * 32].reshape(240, 8, 32)[:, 0]  # first mma wave of every workgroup
+        cyc, wall = t[:, 5] - t[:, 0], (t[:, 13] - t[:, 12]) / 100.0  # cycles, microseconds
+        ok = (cyc > 0) & (wall > 0)
+        return float(np.median(cyc[ok] / wall[ok])) if ok.any() else None
     except Exception:
-        pass
-    finally:
-        stop.set()
-        th.join()
-    return max(vals) if vals else None
+        return None
 
 
 def fence(dist, dev):
@@ -422,7 +413,7 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                 _lib.check(st)
         _lib.check(lib.dad3d_flame_profile_end(handle, stream, C.byref(tot), C.byref(cnt)))
     kern_s = tot.value / max(cnt.value, 1) * 1e-3
-    clock_mhz = observed_shader_clock_mhz(lambda: step(0), dev) if rank == 0 else None
+    clock_mhz = observed_shader_clock_mhz(lib, handle, sets[0]["call"], dev) if rank == 0 else None
     events_s = max_over_ranks(dist, dev, tot.value * 1e-3)  # this rank's K launches on its stream, MAX over ranks
 
     timeouts = C.c_uint()

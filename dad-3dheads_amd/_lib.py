@@ -97,6 +97,8 @@ SIGNATURES = {
     "dad3d_mesh_debug_trace": (_I, [_P, _P]),
     "dad3d_project_vertices": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "dad3d_preprocess_images": (_I, [_P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _I, _P]),
+    "dad3d_nhwc_bias_act": (_I, [_P, _P, _P, C.c_int64, _I, _I, _I, _I, _P]),
+    "dad3d_nhwc_resize_sum": (_I, [_P, _I, _I, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(C.c_float), _I, _P]),
     "dad3d_cube_region_loss": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "dad3d_point_loss_terms": (_I, [_I]),
     "dad3d_weighted_point_loss": (_I, [_P, _P, _I, _I, _I, _P, _F, _I, _P, _P, _I, _P]),

@@ -895,6 +895,37 @@ dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_si
                              static_cast<hipStream_t>(stream));
 }
 
+static int dtype_vec(int dtype) { return dtype == DAD3D_DTYPE_F32 ? 4 : (dtype == DAD3D_DTYPE_F16 || dtype == DAD3D_DTYPE_BF16) ? 8 : 0; }
+
+dad3d_status dad3d_nhwc_bias_act(void* y, const void* bias, const void* z, int64_t n_pixels, int channels, int dtype, int relu,
+                                 int device, void* stream) {
+    DAD3D_REQUIRE(n_pixels >= 0 && channels > 0 && dtype_vec(dtype), "dad3d_nhwc_bias_act: bad argument");
+    if (n_pixels == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(y && bias, "dad3d_nhwc_bias_act: null tensor");
+    DAD3D_REQUIRE(channels % dtype_vec(dtype) == 0, "dad3d_nhwc_bias_act: %d channels are not a multiple of %d (16 bytes)", channels, dtype_vec(dtype));
+    DAD3D_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(z) & 15) == 0, "dad3d_nhwc_bias_act: tensors must be 16-byte aligned");
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    return launch_nhwc_bias_act(y, bias, z, (size_t)n_pixels, channels, dtype, relu, static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_nhwc_resize_sum(void* out, int n, int oh, int ow, int channels, int dtype, int n_inputs, const void* const* xs,
+                                   const int* hs, const int* ws, const float* weights, int device, void* stream) {
+    DAD3D_REQUIRE(n >= 0 && oh >= 0 && ow >= 0 && channels > 0 && dtype_vec(dtype) && n_inputs >= 1 && n_inputs <= 3,
+                  "dad3d_nhwc_resize_sum: bad argument");
+    if (n == 0 || oh == 0 || ow == 0) return DAD3D_OK;
+    DAD3D_REQUIRE(out && xs && hs && ws && weights, "dad3d_nhwc_resize_sum: null argument");
+    DAD3D_REQUIRE(channels % dtype_vec(dtype) == 0, "dad3d_nhwc_resize_sum: %d channels are not a multiple of %d (16 bytes)", channels, dtype_vec(dtype));
+    DAD3D_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "dad3d_nhwc_resize_sum: tensors must be 16-byte aligned");
+    for (int j = 0; j < n_inputs; ++j)
+        DAD3D_REQUIRE(xs[j] && hs[j] > 0 && ws[j] > 0 && (reinterpret_cast<uintptr_t>(xs[j]) & 15) == 0,
+                      "dad3d_nhwc_resize_sum: input %d is null, empty or not 16-byte aligned", j);
+    DeviceGuard guard(device);
+    DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", device);
+    return launch_nhwc_resize_sum(out, n, oh, ow, channels, dtype, n_inputs, xs, hs, ws, weights, static_cast<hipStream_t>(stream));
+}
+
 dad3d_status dad3d_cube_region_loss(const float* pred, const float* target, int batch, int n_verts,
                                     const int32_t* region_ptr, const int32_t* region_idx, const float* region_weight,
                                     int n_regions, const int32_t* vert_ptr, const int32_t* vert_region,

@@ -264,4 +264,10 @@ dad3d_status launch_point_loss(const PointLossArgs& a, hipStream_t s);
 dad3d_status launch_preprocess(const long long* descs, int batch, int out_size, const float mean[3], const float std[3],
                                float* out, hipStream_t s);
 
+// DAD-3DNet glue (cnn_glue.hip): NHWC tensors, dtype = DAD3D_DTYPE_*
+dad3d_status launch_nhwc_bias_act(void* y, const void* bias, const void* z, size_t n_pixels, int channels, int dtype, int relu,
+                                  hipStream_t s);
+dad3d_status launch_nhwc_resize_sum(void* out, int n, int oh, int ow, int channels, int dtype, int n_inputs, const void* const* xs,
+                                    const int* hs, const int* ws, const float* weights, hipStream_t s);
+
 }  // namespace dad3d

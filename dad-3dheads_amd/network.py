@@ -19,8 +19,10 @@ exactly like the reference's predictor does.
 
 `forward` returns the reference's output dict (`OUTPUT_LANDMARKS_HEATMAP`, `OUTPUT_3DMM_PARAMS` [B,413],
 `OUTPUT_2D_LANDMARKS` [B,68,2]: flame_regression.py:100-104).
-Inference runs channels-last in bf16 (MIOpen / hipBLASLt underneath); the 413 parameters are cast to fp32 on the way
-out because the decode computes in fp32. PyTorch is plumbing here: this file contains no custom kernels.
+Inference runs channels-last with bf16 WEIGHTS (converted once, no autocast; MIOpen / hipBLASLt underneath); the 413
+parameters are cast to fp32 on the way
+out because the decode computes in fp32. PyTorch is plumbing here; the elementwise passes it would leave between the
+convolutions (bias, residual, ReLU; the BiFPN's weighted resize-and-sum) go through csrc/cnn_glue.hip when serving.
 """
 from __future__ import annotations
 
@@ -29,6 +31,8 @@ from typing import Dict, List, Sequence
 import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
+
+from . import _glue
 
 # keys of the network's output dict: the VALUES model_training/data/config.py:16-23 gives these names (each constant's
 # value is its own name) -- what the reference's TorchScript checkpoint returns and predictor.py:103-109 looks up
@@ -59,6 +63,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         skip = x if self.shortcut is None else self.shortcut(x)
+        last = self.body[2][0]
+        if isinstance(last, ConvBiasAct):  # serving form: bias + identity + ReLU in one pass behind the last convolution
+            return last(self.body[1](self.body[0](x)), z=skip, relu=True)
         return F.relu(self.body(x) + skip, inplace=True)
 
 
@@ -87,6 +94,8 @@ class SeparableBlock(nn.Module):
         self.bn = nn.BatchNorm2d(ch, momentum=0.9997, eps=4e-5)
 
     def forward(self, x: Tensor) -> Tensor:
+        if isinstance(self.pointwise, ConvBiasAct):  # serving form: depthwise scale and BatchNorm folded in, ReLU fused behind
+            return self.pointwise(x)
         return F.relu(self.bn(self.pointwise(self.depthwise(x))))
 
 
@@ -116,6 +125,19 @@ class BiFPNBlock(nn.Module):
 
     def forward(self, levels: Sequence[Tensor]) -> List[Tensor]:
         p3, p4, p5, p6, p7 = levels
+        if self.frozen is not None and self.__dict__.get("glue") and _glue.supported(p3, p4, p5, p6, p7):
+            # serving form on the GPU: a node's weighted sum WITH its nearest-neighbour resize is one streaming kernel
+            # (csrc/cnn_glue.hip) instead of a scale, a materialised F.interpolate and one or two adds
+            a, b = self.frozen
+            t6 = self.td[0](_glue.resize_sum((a[0][0], a[1][0]), (p6, p7), p6.shape[2:]))
+            t5 = self.td[1](_glue.resize_sum((a[0][1], a[1][1]), (p5, t6), p5.shape[2:]))
+            t4 = self.td[2](_glue.resize_sum((a[0][2], a[1][2]), (p4, t5), p4.shape[2:]))
+            o3 = self.td[3](_glue.resize_sum((a[0][3], a[1][3]), (p3, t4), p3.shape[2:]))
+            o4 = self.out[0](_glue.resize_sum((b[0][0], b[1][0], b[2][0]), (p4, t4, o3), p4.shape[2:]))
+            o5 = self.out[1](_glue.resize_sum((b[0][1], b[1][1], b[2][1]), (p5, t5, o4), p5.shape[2:]))
+            o6 = self.out[2](_glue.resize_sum((b[0][2], b[1][2], b[2][2]), (p6, t6, o5), p6.shape[2:]))
+            o7 = self.out[3](_glue.resize_sum((b[0][3], b[1][3], b[2][3]), (p7, p7, o6), p7.shape[2:]))
+            return [o3, o4, o5, o6, o7]
         if self.frozen is not None:  # inference: the weights are python floats, a weighted sum is two passes, not three
             a, b = self.frozen
             fuse2 = lambda w0, x0, w1, x1: torch.add(w0 * x0, x1, alpha=w1)  # noqa: E731
@@ -300,26 +322,88 @@ def fold_batchnorm(module: nn.Module) -> nn.Module:
     return module
 
 
+class ConvBiasAct(nn.Module):
+    """Serving form of `conv -> (+ bias) -> (+ residual) -> ReLU`: the convolution runs without its bias, then ONE in-place
+    streaming pass (csrc/cnn_glue.hip `dad3d_nhwc_bias_act`) adds the bias -- the folded BatchNorm's shift -- and the identity
+    and clamps. The framework's own sequence was a broadcast add, a second add and a clamp: three memory-bound launches per
+    bottleneck, two behind every other convolution. CPU tensors and shapes the kernel does not take use the plain ops."""
+
+    def __init__(self, conv: nn.Conv2d, relu: bool):
+        super().__init__()
+        self.bias = nn.Parameter(conv.bias.detach().clone(), requires_grad=False)
+        conv.bias = None
+        self.conv = conv
+        self.relu = relu
+
+    def forward(self, x: Tensor, z: Tensor = None, relu: bool = None) -> Tensor:
+        relu = self.relu if relu is None else relu
+        y = self.conv(x)
+        if _glue.supported(y, z) and self.bias.dtype == y.dtype:
+            return _glue.bias_act_(y, self.bias, z, relu)
+        y = y + self.bias.view(1, -1, 1, 1)
+        if z is not None:
+            y = y + z
+        return F.relu(y) if relu else y
+
+
+def fuse_glue(module: nn.Module) -> nn.Module:
+    """Inference-only rewrite, in place, AFTER fold_batchnorm: every biased Conv2d of a Sequential becomes a ConvBiasAct that
+    also takes the ReLU behind it; folded separable blocks and the BiFPN's fusion nodes switch to their one-pass forms."""
+    for child in module.children():
+        fuse_glue(child)
+    if isinstance(module, nn.Sequential):
+        mods = list(module.children())
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Conv2d) and m.bias is not None:
+                j = i + 1
+                while j < len(mods) and isinstance(mods[j], nn.Identity):
+                    j += 1
+                relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+                module[i] = ConvBiasAct(m, relu)
+                if relu:
+                    module[j] = nn.Identity()
+                    mods[j] = module[j]
+    if isinstance(module, Bottleneck) and module.shortcut is not None and isinstance(module.body[2][0], ConvBiasAct) \
+            and isinstance(module.shortcut[0], ConvBiasAct):
+        # the projection shortcut's shift joins the last convolution's: the shortcut needs no pass of its own
+        with torch.no_grad():
+            module.body[2][0].bias.add_(module.shortcut[0].bias)
+        module.shortcut[0] = module.shortcut[0].conv  # bias already None
+    if isinstance(module, SeparableBlock) and isinstance(module.depthwise, nn.Identity) and isinstance(module.bn, nn.Identity) \
+            and isinstance(module.pointwise, nn.Conv2d) and module.pointwise.bias is not None:
+        module.pointwise = ConvBiasAct(module.pointwise, True)
+    if isinstance(module, BiFPNBlock) and module.frozen is not None:
+        module.__dict__["glue"] = True
+    return module
+
+
 class InferenceNet(nn.Module):
     """`DAD3DNet` frozen for serving: eval mode, BatchNorm folded into the convolutions, channels-last, reduced-precision
     autocast; fp32 parameters out. `tune=True` lets MIOpen time its kernels per layer shape on the first call (+36 % at
     batch 64, first call ~17 s)."""
 
-    def __init__(self, net: nn.Module, dtype: torch.dtype = torch.bfloat16, fold_bn: bool = True, tune: bool = False):
+    def __init__(self, net: nn.Module, dtype: torch.dtype = torch.bfloat16, fold_bn: bool = True, tune: bool = False,
+                 glue: bool = True):
         super().__init__()
         net = net.eval()
         if fold_bn:
             fold_batchnorm(net)
-        self.net = net.to(memory_format=torch.channels_last)
+            if glue:
+                fuse_glue(net)
+        # Reduced precision by converting the WEIGHTS once, not by autocast: under autocast every forward re-cast every fp32
+        # weight (175 copy kernels per batch) and the BiFPN's resize / weighted sums ran in fp32 between casts
+        # (profiles/r03_cnn_kernels.txt: 30 % of the forward's kernel time). Measured and NOT done: convolution + bias + ReLU and
+        # convolution + residual + ReLU through torch.miopen_convolution_relu / _add_relu -- for channels-last bf16 MIOpen's
+        # fusion plans fall back to its naive reference convolution (860 ms per batch of 64 instead of 7).
+        self.net = net.to(dtype).to(memory_format=torch.channels_last) if dtype != torch.float32 else net.to(memory_format=torch.channels_last)
         self.dtype = dtype
         if tune:
             torch.backends.cudnn.benchmark = True  # MIOpen find mode on ROCm
 
     @torch.no_grad()
     def forward(self, x: Tensor) -> Dict[str, Tensor]:
-        x = x.contiguous(memory_format=torch.channels_last)
-        with torch.autocast(device_type=x.device.type, dtype=self.dtype, enabled=self.dtype != torch.float32):
-            out = self.net(x)
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        out = self.net(x)
         return {k: v.float() for k, v in out.items()}
 
 

@@ -302,6 +302,22 @@ dad3d_status dad3d_weighted_point_loss(const float* pred, const float* target, i
 dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_size, const float* mean, const float* std,
                                      float* out, int device, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Glue of the DAD-3DNet forward between the framework's convolutions (the network itself stays on PyTorch-ROCm): channels-last
+ * (NHWC, dense) DEVICE tensors of fp32 / fp16 / bf16 elements; `channels` a multiple of 16 bytes' worth (4 / 8).
+ *   dad3d_nhwc_bias_act    y = act(y + bias[c] (+ z)), in place: the folded BatchNorm's shift, the bottleneck's identity and the
+ *                          ReLU behind a convolution in ONE pass (model_training/model/layers.py conv-bn-relu blocks; pytorchcv's
+ *                          ResUnit `x = body(x) + identity; x = activ(x)`, built at model_training/model/encoders.py:42-48)
+ *   dad3d_nhwc_resize_sum  out = sum_k weights[k] * nearest_resize(x_k -> [oh, ow]), k < n_inputs <= 3: a BiFPN node's weighted
+ *                          fusion with its F.interpolate folded in (model_training/model/bifpn.py:98-125) */
+#define DAD3D_DTYPE_F32 0
+#define DAD3D_DTYPE_F16 1
+#define DAD3D_DTYPE_BF16 2
+dad3d_status dad3d_nhwc_bias_act(void* y, const void* bias, const void* z /* or NULL */, int64_t n_pixels, int channels, int dtype,
+                                 int relu, int device, void* stream);
+dad3d_status dad3d_nhwc_resize_sum(void* out, int n, int oh, int ow, int channels, int dtype, int n_inputs, const void* const* xs,
+                                   const int* hs, const int* ws, const float* weights, int device, void* stream);
+
 /* Single-image HOST entry points with the argument lists of Sim3DR/lib/rasterize.h:84-100 (`bool` spelled
  * `int` for C). libdad3d_hip.so additionally exports the C++-linkage symbols `_get_tri_normal`,
  * `_get_ver_normal`, `_get_normal`, `_rasterize_triangles`, `_rasterize` with the reference's exact

@@ -184,6 +184,74 @@ def test_68_landmarks_on_device_equal_host(net_predictor, static):
     assert seven_landmarks(on_dev).shape == (5, 7, 3)
 
 
+def test_cnn_glue_kernels_equal_the_framework_ops():
+    """csrc/cnn_glue.hip through its C ABI: bias (+ residual) (+ ReLU) in place and the BiFPN's weighted nearest-resize-and-sum,
+    against the torch statements they replace (layers of model_training/model/layers.py; bifpn.py:98-125), for the three
+    element types, up- and down-sampling, odd extents."""
+    import torch.nn.functional as F
+
+    from dad_3dheads_amd import _glue
+
+    g = torch.Generator().manual_seed(11)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+        for shape in ((3, 64, 17, 9), (2, 256, 8, 8), (1, 2048, 1, 1)):
+            y = torch.randn(shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+            z = torch.randn(shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+            b = torch.randn(shape[1], generator=g).cuda().to(dtype)
+            assert _glue.supported(y, z)
+            for zz in (None, z):
+                for relu in (False, True):
+                    want = y.float() + b.float().view(1, -1, 1, 1) + (zz.float() if zz is not None else 0)
+                    want = F.relu(want) if relu else want
+                    got = _glue.bias_act_(y.clone(memory_format=torch.channels_last), b, zz, relu)
+                    assert got.is_contiguous(memory_format=torch.channels_last)
+                    assert float((got.float() - want).abs().max()) <= tol * max(float(want.abs().max()), 1.0)
+        xs = [torch.randn(2, 64, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+              for h, w in ((16, 16), (8, 8), (32, 31))]
+        ws = (0.43, 0.31, 0.27)
+        for size in ((16, 16), (8, 8), (5, 7), (32, 31)):
+            for k in (1, 2, 3):
+                want = sum(ws[j] * F.interpolate(xs[j].float(), size=size) for j in range(k))
+                got = _glue.resize_sum(ws[:k], xs[:k], size)
+                assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+                assert float((got.float() - want).abs().max()) <= tol * max(float(want.abs().max()), 1.0), (dtype, size, k)
+    assert not _glue.supported(torch.zeros(1, 68, 4, 4, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert not _glue.supported(torch.zeros(1, 64, 4, 4, device="cuda"))  # NCHW
+
+
+def test_inference_net_equals_the_plain_module_on_the_gpu():
+    """InferenceNet's serving rewrite -- BatchNorm folded, BiFPN weights frozen, channels-last, weights converted ONCE to the
+    serving dtype instead of autocast -- against the plain fp32 module on the same device (fp32: rounding only; bf16: the
+    precision of the format)."""
+    import copy
+
+    from dad_3dheads_amd.network import DAD3DNet, InferenceNet
+
+    base = DAD3DNet(seed=3).eval()
+    with torch.no_grad():  # BatchNorm statistics away from their initial values so that the folding does something
+        for m in base.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2), m.running_var.uniform_(0.6, 1.4), m.weight.uniform_(0.7, 1.3), m.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        want = copy.deepcopy(base).cuda()(x)
+    got = InferenceNet(copy.deepcopy(base), torch.float32).cuda()(x)
+    for k in want:
+        assert float((got[k] - want[k]).abs().max()) < 2e-3 * max(float(want[k].abs().max()), 1.0), k
+    from dad_3dheads_amd.network import ConvBiasAct
+
+    plain = InferenceNet(copy.deepcopy(base), torch.float32, glue=False).cuda()(x)  # the same rewrite on the framework's own ops
+    for k in want:
+        assert float((got[k] - plain[k]).abs().max()) < 1e-4 * max(float(want[k].abs().max()), 1.0), k
+    low_net = InferenceNet(copy.deepcopy(base), torch.bfloat16).cuda()
+    assert sum(isinstance(m, ConvBiasAct) for m in low_net.modules()) > 60
+    assert all(p.dtype == torch.bfloat16 for p in low_net.parameters())
+    low = low_net(x)
+    for k in want:
+        assert low[k].dtype == torch.float32 and torch.isfinite(low[k]).all()
+        assert float((low[k] - want[k]).abs().max()) < 0.15 * max(float(want[k].abs().max()), 1.0), k
+
+
 def test_graphed_network_equals_eager(flame_model):
     """GraphedNet: the frozen CNN replayed from a hipGraph (one per input shape) gives the eager outputs."""
     from dad_3dheads_amd.network import DAD3DNet, GraphedNet, InferenceNet
