@@ -18,15 +18,24 @@ namespace {
 constexpr int kCoefBits = 11;  // INTER_RESIZE_COEF_BITS
 
 // cv2's coefficient set-up for one destination coordinate (resize.cpp, the `interpolation == INTER_LINEAR` branch of
-// resize(): fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx; borders clamp with fx = 0;
+// resize(): fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx;
 // ialpha = saturate_cast<short>(coef * INTER_RESIZE_COEF_SCALE) = round-half-even).
-__device__ __forceinline__ void linear_tap(int d, int src_n, int dst_n, int& s, int& c0, int& c1) {
+// HORIZONTAL only: at the borders resize() sets (fx, sx) = (0, 0) resp. (0, src - 1). For the rows it keeps the fractional
+// part and clamps only the two row INDICES (`clip(sy + k, 0, ssize.height)` in the row loop): above the first and below the
+// last source row both taps read the same row with weights that still sum to 2048 -- one LSB away from a zeroed fraction
+// on some pixels of an up-scaled image's first and last rows.
+template <bool HORIZONTAL>
+__device__ __forceinline__ void linear_tap(int d, int src_n, int dst_n, int& s0, int& s1, int& c0, int& c1) {
     const double scale = 1.0 / ((double)dst_n / (double)src_n);
     float f = (float)(((double)d + 0.5) * scale - 0.5);
-    s = (int)floorf(f);
+    int s = (int)floorf(f);
     f -= (float)s;
-    if (s < 0) f = 0.0f, s = 0;
-    if (s >= src_n - 1) f = 0.0f, s = src_n - 1;
+    if (HORIZONTAL) {
+        if (s < 0) f = 0.0f, s = 0;
+        if (s >= src_n - 1) f = 0.0f, s = src_n - 1;
+    }
+    s0 = min(max(s, 0), src_n - 1);
+    s1 = min(max(s + 1, 0), src_n - 1);
     c0 = __float2int_rn((1.0f - f) * (float)(1 << kCoefBits));
     c1 = __float2int_rn(f * (float)(1 << kCoefBits));
 }
@@ -48,10 +57,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const long long* __rest
             const unsigned char* p = src + dy * row_stride + 3 * dx;
             r = p[0], g = p[1], bl = p[2];
         } else {
-            int sx, a0, a1, sy, b0, b1;
-            linear_tap(dx, w, nw, sx, a0, a1);
-            linear_tap(dy, h, nh, sy, b0, b1);
-            const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+            int sx, sx1, a0, a1, sy, sy1, b0, b1;
+            linear_tap<true>(dx, w, nw, sx, sx1, a0, a1);
+            linear_tap<false>(dy, h, nh, sy, sy1, b0, b1);
             const unsigned char* p00 = src + sy * row_stride + 3 * sx;
             const unsigned char* p01 = src + sy * row_stride + 3 * sx1;
             const unsigned char* p10 = src + sy1 * row_stride + 3 * sx;

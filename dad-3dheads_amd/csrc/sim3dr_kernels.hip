@@ -403,6 +403,8 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const Normal
         ext[k] = bd[3 + k] - bd[k];
         gmax = fmaxf(gmax, ext[k]);
     }
+    const int int_exp = (int)cfg.specular_exp;
+    const bool small_int_exp = (float)int_exp == cfg.specular_exp && int_exp >= 3 && int_exp <= 64;
     for (int v = v0; v < v_end; v += kStageThreads) {
     AdjRow cur;
     SlotRow scur;
@@ -449,9 +451,24 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const Normal
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float refl = 2.0f * cosv * n[k] - d[k];
-                // np.power(float32 array, scalar): exact fast paths for 1 (copy) and 2 (square), libm / SVML powf otherwise
+                // np.power(float32 array, scalar): exact fast paths for 1 (copy) and 2 (square), libm / SVML powf otherwise.
+                // The host's powf is within an ulp of the true power, and so is a product chain for a small integer exponent
+                // (the default is 5: t, t^2, t^4, t^5 -- three multiplications instead of ~100 instructions of a general powf,
+                // three times per vertex); neither reproduces the other's last bit, both are far inside the 2e-5 the byte
+                // check of tests/render_checks.py explains.
                 const float t = e[k] * refl;
-                spe += cfg.specular_exp == 2.0f ? t * t : cfg.specular_exp == 1.0f ? t : powf(t, cfg.specular_exp);
+                float pw;
+                if (cfg.specular_exp == 2.0f) pw = t * t;
+                else if (cfg.specular_exp == 1.0f) pw = t;
+                else if (small_int_exp) {
+                    float base = t;
+                    pw = 1.0f;
+                    for (int ee = int_exp; ee; ee >>= 1) {
+                        if (ee & 1) pw *= base;
+                        base *= base;
+                    }
+                } else pw = powf(t, cfg.specular_exp);
+                spe += pw;
             }
             spe = (cosv != 0.0f) ? clip01(spe) : 0.0f;
 #pragma unroll

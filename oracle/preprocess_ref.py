@@ -9,7 +9,8 @@ own C++ by one LSB on some pixels. What is restated is the published C++ path an
   OpenCV modules/imgproc/src/resize.cpp, resize() with INTER_LINEAR on CV_8UC3:
       inv_scale = dst / src (double); scale = 1 / inv_scale
       per destination coordinate d: f = (float)((d + 0.5) * scale - 0.5); s = cvFloor(f); f -= s
-          s < 0 -> (f, s) = (0, 0);  s >= src - 1 -> (f, s) = (0, src - 1)
+          columns only: s < 0 -> (f, s) = (0, 0);  s >= src - 1 -> (f, s) = (0, src - 1); rows keep f, the row loop clamps
+          the two row indices (round 3, ADVICE: rounds 1-2 zeroed the fraction for the rows too)
           coefficients = saturate_cast<short>((1 - f) * 2048), saturate_cast<short>(f * 2048)        (round half to even)
       HResizeLinear<uchar,int,short>:  row[d] = S[s] * c0 + S[s + 1] * c1
       VResizeLinear<uchar,int,short>:  dst = (((b0 * (row0 >> 4)) >> 16) + ((b1 * (row1 >> 4)) >> 16) + 2) >> 2
@@ -41,18 +42,21 @@ def geometry(h: int, w: int, size: int = 256):
     return nh, nw, int((m - nh) / 2), int((m - nw) / 2), scale
 
 
-def _taps(dst_n: int, src_n: int):
+def _taps(dst_n: int, src_n: int, horizontal: bool):
+    """resize()'s coefficient set-up. Only the HORIZONTAL taps get (f, s) = (0, border) at the image borders; for the rows the
+    fraction is kept and the two row indices are clamped in the row loop (`clip(sy + k, 0, ssize.height)`)."""
     scale = 1.0 / (float(dst_n) / float(src_n))
     d = np.arange(dst_n, dtype=np.float64)
     f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
     f = f - s.astype(np.float32)
-    lo, hi = s < 0, s >= src_n - 1
-    f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
-    s = np.where(lo, 0, np.where(hi, src_n - 1, s))
+    if horizontal:
+        lo, hi = s < 0, s >= src_n - 1
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        s = np.where(lo, 0, np.where(hi, src_n - 1, s))
     c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)  # cvRound: half to even
     c1 = np.rint(f * np.float32(2048)).astype(np.int64)
-    return s, np.minimum(s + 1, src_n - 1), c0, c1
+    return np.clip(s, 0, src_n - 1), np.clip(s + 1, 0, src_n - 1), c0, c1
 
 
 def resize_linear_u8(img: np.ndarray, nh: int, nw: int) -> np.ndarray:
@@ -61,8 +65,8 @@ def resize_linear_u8(img: np.ndarray, nh: int, nw: int) -> np.ndarray:
     h, w = img.shape[:2]
     if (nh, nw) == (h, w):
         return img.copy()
-    sx, sx1, a0, a1 = _taps(nw, w)
-    sy, sy1, b0, b1 = _taps(nh, h)
+    sx, sx1, a0, a1 = _taps(nw, w, True)
+    sy, sy1, b0, b1 = _taps(nh, h, False)
     src = img.astype(np.int64)
     rows = src[:, sx, :] * a0[None, :, None] + src[:, sx1, :] * a1[None, :, None]  # [h, nw, c]
     r0, r1 = rows[sy], rows[sy1]
