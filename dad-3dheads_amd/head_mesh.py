@@ -9,8 +9,12 @@ passes) is staged through the GPU and returned as a CPU tensor; a CUDA tensor ne
 landmarks, where the reference runs two full decodes (predictor.py:136-137).
 
 Training callers (`losses/vertices_3d_loss.py:41`, `losses/reprojection_loss.py:33`) pass a tensor that requires grad:
-`vertices_3d` / `reprojected_vertices` then go through `autograd.decode_with_grad` (same forward launch, backward in
-the library + two rocBLAS GEMMs) and the result carries a grad_fn like the reference's.
+`vertices_3d` / `reprojected_vertices` then go through `autograd.decode_with_grad` (same forward launch; backward = the
+library's per-vertex and pose-chain kernels plus ONE GEMM dL/d(v_posed) . basis^T -- the hand-written split-K MFMA kernel up
+to batch 96, rocBLAS above) and the result carries a grad_fn like the reference's.
+
+`flame.compat_cross_b3 = True` opts into the reference's batch-of-exactly-three behaviour (`torch.cross` without `dim`,
+model_training/model/utils.py:98-99, crosses over the batch axis); by default every image gets its own rotation.
 """
 from __future__ import annotations
 
