@@ -4,7 +4,7 @@
 export TMPDIR=/tmp; root="${GRAFT_REPO_ROOT:-/root/repo}"
 for v in "$@"; do
   if [ "$v" = product ]; then unset DAD3D_LIB_PATH; else export DAD3D_LIB_PATH="$root/tools/_variants/lib_$v.so"; fi
-  rm -rf /tmp/ps_$v; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps_$v -- python $root/tools/ab_sim3dr.py $v > /tmp/ps_$v.log 2>&1)
+  rm -rf /tmp/ps_$v; (cd /tmp && timeout 90 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps_$v -- python $root/tools/ab_sim3dr.py $v > /tmp/ps_$v.log 2>&1)
   f=$(find /tmp/ps_$v -name "*kernel_stats.csv" | head -1)
   echo "== $v: $(grep AB3D /tmp/ps_$v.log | sed 's/.*normals_exact/normals_exact/')"
   python3 - "$f" <<'PY'
