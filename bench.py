@@ -238,7 +238,19 @@ def make_direct_gather(dist):
         return None
     from dad_3dheads_amd.rccl import RcclAllGather
 
-    return RcclAllGather()
+    try:
+        ok, direct = 1, RcclAllGather()
+    except Exception as e:  # never lose a multi-GPU run to the shortcut: the process group's own all-gather is always there
+        print(f"bench.py: direct RCCL gather unavailable ({type(e).__name__}: {e}); using torch.distributed", file=sys.stderr)
+        ok, direct = 0, None
+    # every rank must take the same path (the collectives have to match): all-reduce the outcome
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if direct is not None:
+            direct.destroy()
+        return None
+    return direct
 
 
 def time_gather(gather, dev, n: int = 20) -> float:
