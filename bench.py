@@ -292,7 +292,11 @@ def observed_shader_clock_mhz(lib, handle, call, dev):
 
 
 def fence(dist, dev):
+    """barrier + synchronize. The device is drained FIRST when a process group is up: the direct RCCL gather (its own
+    communicator, on the launch stream) has then finished on this rank before the group's barrier kernel is queued -- two
+    communicators are never in flight together on one GPU."""
     if dist is not None:
+        torch.cuda.synchronize(dev)
         dist.barrier()
     torch.cuda.synchronize(dev)
 
