@@ -6,7 +6,8 @@ shows it: vertices exactly on pixel centres (the strict `> 0` interior test of _
 _rasterize_triangles), zero-area and sliver triangles (inv = 0 or huge: NaN / inf barycentrics), exact depth ties between
 triangles that land in DIFFERENT 64 x 64 tiles and in split tiles (tie -> lowest triangle index), boxes that straddle tile
 borders and the image edge, triangles as large as the image next to hundreds of tiny ones (every area class of the lane
-allocation in one list), repeated indices, huge coordinates. Shrunk counter-examples, if any ever appear, belong in
+allocation in one list), repeated indices, huge coordinates, stacked sheets of either winding (the two-pass culling of
+long tile lists). Shrunk counter-examples, if any ever appear, belong in
 tests/golden/ (none so far)."""
 import numpy as np
 import pytest
@@ -18,7 +19,7 @@ from dad_3dheads_amd.Sim3DR import Mesh
 
 pytestmark = pytest.mark.gpu
 
-PROFILES = ("pixel_centres", "slivers", "tie_planes", "tile_straddle", "mixed_sizes", "split_tile", "wild")
+PROFILES = ("pixel_centres", "slivers", "tie_planes", "tile_straddle", "mixed_sizes", "split_tile", "wild", "layers")
 
 
 def build_case(seed: int, profile: str):
@@ -76,6 +77,34 @@ def build_case(seed: int, profile: str):
         v[:, 1] = rng.uniform(-4, 70, nver)
         v[:, 2] = np.round(rng.uniform(-3, 3, nver))
         t = rng.integers(0, nver, (ntri, 3)).astype(np.int32)
+    elif profile == "layers":  # sheets of opposite winding over the same pixels, tile lists long enough for the two-pass
+        # path of the tile kernel (far-facing triangles culled against what the near-facing ones left): exact depth ties
+        # between the sheets, sheets that cross, either winding in front, a sheet of mixed winding, a pre-filled depth buffer
+        h, w = int(rng.integers(70, 140)), int(rng.integers(70, 200))
+        g = int(rng.integers(12, 18))
+        sheets_v, sheets_t = [], []
+        level = rng.permutation([0.0, 0.0, 1.0, -1.0])[:3]  # two sheets may share a depth plane
+        for k in range(3):
+            gx, gy = np.meshgrid(np.linspace(-4, w * rng.uniform(0.6, 1.05), g), np.linspace(-4, h * rng.uniform(0.6, 1.05), g))
+            jit = rng.uniform(-1.2, 1.2, (2,) + gx.shape) * (rng.random(gx.shape) < 0.7)
+            px, py = gx + jit[0], gy + jit[1]
+            if k == 1:
+                px, py = np.round(px), np.round(py)
+            z = level[k] + np.round(rng.uniform(-1, 1, gx.shape) * 2) / 2 * (rng.random(gx.shape) < 0.4) + float(rng.choice([0.0, 0.02])) * gx
+            sv = np.stack([px.ravel(), py.ravel(), z.ravel()], 1)
+            i = (np.arange(g - 1)[:, None] * g + np.arange(g - 1)[None]).ravel()
+            st_ = np.concatenate([np.stack([i, i + 1, i + g], 1), np.stack([i + 1, i + g + 1, i + g], 1)])
+            if k == 1:
+                st_ = st_[:, ::-1]
+            if k == 2:
+                flip = rng.random(len(st_)) < 0.5
+                st_[flip] = st_[flip][:, ::-1]
+            sheets_t.append(st_ + sum(len(q) for q in sheets_v))
+            sheets_v.append(sv)
+        v = np.concatenate(sheets_v).astype(np.float32)
+        t = np.concatenate(sheets_t).astype(np.int32)
+        t = t[rng.permutation(len(t))]
+        nver = len(v)
     elif profile == "wild":  # huge and non-finite-producing coordinates next to ordinary ones
         v[rng.integers(0, nver, 3), 0] = rng.choice([1e7, -1e7, 3e38, -3e38, 65535.5])
         v[rng.integers(0, nver, 2), 1] = rng.choice([1e7, -3e38])
@@ -86,17 +115,22 @@ def build_case(seed: int, profile: str):
     return np.ascontiguousarray(v, np.float32), np.ascontiguousarray(t), col, bg, h, w, bool(rng.integers(0, 2))
 
 
-@settings(max_examples=42, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=56, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), profile=st.sampled_from(PROFILES))
 def test_raster_and_normals_fuzz_bit_exact(sim3dr_oracle, seed, profile):
     v, t, col, bg, h, w, rev = build_case(seed, profile)
     mesh = Mesh(t, v.shape[0], device=0)
     dv = torch.from_numpy(v).cuda()[None]
     img = torch.from_numpy(bg.copy()).cuda()[None].contiguous()
-    depth = torch.full((1, h, w), -1e8, device="cuda")
+    depth0 = np.full((h, w), -1e8, np.float32)
+    if profile == "layers" and seed % 2:  # something already drawn in front of / level with / behind the sheets
+        depth0[h // 4 : h // 2, :] = 0.0
+        depth0[:, w // 3 : w // 2] = 2.5
+        depth0[h // 2 :, : w // 4] = np.float32(seed % 5) / 4 - 1
+    depth = torch.from_numpy(depth0.copy()).cuda()[None]
     mesh.rasterize(dv, torch.from_numpy(col).cuda()[None], img, depth=depth, reverse=rev)
     with np.errstate(all="ignore"):
-        ref_img, ref_depth = sim3dr_oracle.rasterize(v, t, col, bg=bg.copy(), reverse=rev, return_depth=True)
+        ref_img, ref_depth = sim3dr_oracle.rasterize(v, t, col, bg=bg.copy(), reverse=rev, depth=depth0.copy(), return_depth=True)
         rd, rtb, rbw = sim3dr_oracle.rasterize_triangles(v, t, h, w)
         ref_n = sim3dr_oracle.get_normal(v, t)
     assert np.array_equal(img[0].cpu().numpy(), ref_img), (profile, seed)
