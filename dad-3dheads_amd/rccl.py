@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -53,7 +54,7 @@ def _check(lib, status: int, what: str) -> None:
 class RcclAllGather:
     """One RCCL communicator over the ranks of `group` (default: the world), one device per rank (the current one)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, init_timeout_s: float = 120.0):
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()):
@@ -61,8 +62,18 @@ class RcclAllGather:
         if not torch.cuda.is_available():
             raise RuntimeError("RcclAllGather needs a GPU")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool's host driver
-        self.lib = _load()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.comm = C.c_void_p()
+        # Every rank must enter ncclCommInitRank or none: a rank that cannot even load the library would leave the others
+        # waiting in it for ever. Agree on that first, through the group that exists (object collectives: any backend).
+        try:
+            self.lib, err = _load(), None
+        except (OSError, RuntimeError, AttributeError) as e:
+            self.lib, err = None, f"rank {self.rank}: {e}"
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err, group=group)
+        if any(errs):
+            raise RuntimeError("RcclAllGather: librccl.so unusable on " + "; ".join(e for e in errs if e))
         uid = _UniqueId()
         if self.rank == 0:
             _check(self.lib, self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
@@ -72,8 +83,24 @@ class RcclAllGather:
         if not isinstance(box[0], bytes) or len(box[0]) != 128:
             raise RuntimeError("RcclAllGather: the unique id did not arrive")
         C.memmove(C.byref(uid), box[0], 128)
-        self.comm = C.c_void_p()
-        _check(self.lib, self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        # The rendezvous itself runs on a helper thread with a deadline (ctypes releases the GIL): a bootstrap that never
+        # completes must surface as an error the caller can fall back from, not as a hung job. The thread needs the rank's
+        # device selected -- the communicator binds to the calling thread's current device.
+        device, done = torch.cuda.current_device(), {}
+
+        def rendezvous():
+            torch.cuda.set_device(device)
+            comm = C.c_void_p()
+            done["status"] = self.lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+            done["comm"] = comm
+
+        worker = threading.Thread(target=rendezvous, name="rccl-init", daemon=True)
+        worker.start()
+        worker.join(init_timeout_s)
+        if "status" not in done:
+            raise TimeoutError(f"ncclCommInitRank did not return within {init_timeout_s:.0f} s (rank {self.rank} of {self.world})")
+        _check(self.lib, done["status"], "ncclCommInitRank")
+        self.comm = done["comm"]
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
         """out[r * n : (r + 1) * n] = rank r's `inp` (n = inp.numel(), any dtype: moved as bytes), queued on `stream`
