@@ -1,7 +1,7 @@
 // Memory-bound glue of the DAD-3DNet forward (the step in front of the decode hot path) as two fused streaming
 // kernels for gfx950. The network itself stays on PyTorch-ROCm (MIOpen / hipBLASLt); what the framework leaves between its
 // convolutions is separate elementwise launches -- at batch 64 they were 60 % of the forward's kernel time
-// (profiles/r03_cnn_kernels.txt): a broadcast bias add and a clamp behind every convolution, a third pass for the residual,
+// (profiles/r03_kernel_log.md section 5; the mix with these kernels: profiles/r03_cnn_kernels_after.txt): a broadcast bias add and a clamp behind every convolution, a third pass for the residual,
 // and for every BiFPN node a scale, a materialised nearest-neighbour resize and one or two adds.
 //
 //   nhwc_bias_act      y = act(y + bias[c] (+ z))       in place on the convolution's output      model_training/model/layers.py

@@ -392,7 +392,7 @@ class InferenceNet(nn.Module):
                 fuse_glue(net)
         # Reduced precision by converting the WEIGHTS once, not by autocast: under autocast every forward re-cast every fp32
         # weight (175 copy kernels per batch) and the BiFPN's resize / weighted sums ran in fp32 between casts
-        # (profiles/r03_cnn_kernels.txt: 30 % of the forward's kernel time). Measured and NOT done: convolution + bias + ReLU and
+        # (profiles/r03_kernel_log.md section 5: 30 % of the forward's kernel time). Measured and NOT done: convolution + bias + ReLU and
         # convolution + residual + ReLU through torch.miopen_convolution_relu / _add_relu -- for channels-last bf16 MIOpen's
         # fusion plans fall back to its naive reference convolution (860 ms per batch of 64 instead of 7).
         self.net = net.to(dtype).to(memory_format=torch.channels_last) if dtype != torch.float32 else net.to(memory_format=torch.channels_last)
