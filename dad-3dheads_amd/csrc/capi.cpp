@@ -84,7 +84,12 @@ static dad3d_status grad_inputs_prepare(dad3d_flame* h, int batch, hipStream_t s
     const int pad = (batch + kBlockImages - 1) / kBlockImages * kBlockImages;
     const int per_slice = grad_chunks_per_slice(pad);
     const size_t rows = (size_t)((grad_chunks(h) + per_slice - 1) / per_slice) * pad;
-    const bool need_pack = h->c->d_gpack == nullptr, need_scratch = rows > h->grad_cap;
+    bool need_pack;
+    {   // forks share the pack: the pointer is only ever looked at under its mutex
+        std::lock_guard<std::mutex> lock(h->c->gpack_mutex);
+        need_pack = h->c->d_gpack == nullptr;
+    }
+    const bool need_scratch = rows > h->grad_cap;
     if (!need_pack && !need_scratch) return DAD3D_OK;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
@@ -365,7 +370,11 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     DAD3D_REQUIRE(!((flags & DAD3D_FLIP_Z) && (flags & DAD3D_TO_2D)), "DAD3D_FLIP_Z needs a 3-component projection");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (posed) {  // a training forward: what its backward pass needs exists before any of it can be captured into a graph
+    // A training forward: what its backward pass needs exists before any of it can be captured into a graph -- for the batches
+    // the host mirror sends to dad3d_flame_grad_inputs (up to DAD3D_GRAD_INPUTS_MAX_BATCH; above it takes the library GEMM and
+    // the split-K scratch, tens to hundreds of MB, would never be used) and for models the kernel covers (otherwise the
+    // forward must not fail for a backward path that will not be taken: dad3d_flame_grad_inputs reports it when called).
+    if (posed && batch <= DAD3D_GRAD_INPUTS_MAX_BATCH && h->n_betas + 36 <= kGradRows) {
         dad3d_status st = grad_inputs_prepare(h, batch, s);
         if (st) return st;
     }
@@ -541,7 +550,8 @@ dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, in
     DAD3D_REQUIRE(grad_posed && grad_inputs, "dad3d_flame_grad_inputs: null argument");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dad3d_status st = grad_inputs_prepare(h, batch, s);  // a no-op after the training forward of the same batch size
+    // a no-op after the training forward of the same batch size (up to DAD3D_GRAD_INPUTS_MAX_BATCH; larger batches allocate here)
+    dad3d_status st = grad_inputs_prepare(h, batch, s);
     if (st) return st;
     const int pad = (batch + kBlockImages - 1) / kBlockImages * kBlockImages;
     const int per_slice = grad_chunks_per_slice(pad);

@@ -14,6 +14,7 @@ from typing import Any, Dict, List, Sequence, Tuple, Union
 import numpy as np
 import torch
 from torch import Tensor, nn
+from torch.autograd.function import once_differentiable
 
 from .head_mesh import HeadMesh
 
@@ -57,6 +58,11 @@ class RegionTables:
         for i in idx:
             if i.size and (i.min() < -n_verts or i.max() >= n_verts):
                 raise IndexError(f"region index out of range for {n_verts} vertices")
+        for k, i in enumerate(idx):
+            # the reference's criterion is a mean over the region's vertices: NaN for an empty one (and NaN gradients for the
+            # whole step). The kernels would add 0 instead -- refused rather than silently different.
+            if i.size == 0:
+                raise ValueError(f"region {k} has no vertices (the reference's mean over it is NaN)")
         idx = [np.where(i < 0, i + n_verts, i) for i in idx]  # python-style negative indices, like tensor[:, i]
         ptr = np.zeros(len(idx) + 1, dtype=np.int32)
         ptr[1:] = np.cumsum([i.size for i in idx])
@@ -83,6 +89,15 @@ def _stage(t: Tensor, device: torch.device) -> Tensor:
     return t.detach().to(device, torch.float32).contiguous()
 
 
+def _first_order_pred_only(ctx) -> None:
+    """The fused kernels return dL/d(pred) as a constant: no gradient for the target, none of second order (the backward
+    passes below are @once_differentiable, so a double backward raises instead of yielding zeros). The reference's torch graph
+    gives both; a caller that needs them evaluates `normalize_to_cube` + the torch criterion instead."""
+    if ctx.needs_input_grad[1]:
+        raise RuntimeError("the HIP mesh losses differentiate with respect to the prediction only: detach the target "
+                           "(the reference's targets are dataset tensors)")
+
+
 class _CubeRegionLoss(torch.autograd.Function):
     """vertices_3d_loss.py:43-49 on decoded vertices: one HIP launch for the value, one more for dL/d(pred)."""
 
@@ -95,6 +110,7 @@ class _CubeRegionLoss(torch.autograd.Function):
         if p.shape != t.shape or p.ndim != 3 or p.shape[1:] != (tables.n_verts, 3):
             raise ValueError(f"expected two [B,{tables.n_verts},3] tensors, got {tuple(pred.shape)} and {tuple(target.shape)}")
         b = p.shape[0]
+        _first_order_pred_only(ctx)
         need_grad = ctx.needs_input_grad[0]
         grad = torch.empty_like(p) if need_grad else None
         stats = torch.empty((tables.n_regions, b, 28), dtype=torch.float32, device=dev)
@@ -110,6 +126,7 @@ class _CubeRegionLoss(torch.autograd.Function):
         return terms.sum().to(pred.device)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         (grad,) = ctx.saved_tensors
         return (grad * g.to(grad.device)).to(ctx.src_device), None, None, None
@@ -127,6 +144,7 @@ class _WeightedPointLoss(torch.autograd.Function):
         if p.shape != t.shape or p.ndim != 3 or p.shape[1] != tables.n_verts:
             raise ValueError(f"expected two [B,{tables.n_verts},C] tensors, got {tuple(pred.shape)} and {tuple(target.shape)}")
         b, comps = p.shape[0], p.shape[2]
+        _first_order_pred_only(ctx)
         need_grad = ctx.needs_input_grad[0]
         grad = torch.empty_like(p) if need_grad else None
         lib = _lib.load()
@@ -140,6 +158,7 @@ class _WeightedPointLoss(torch.autograd.Function):
         return terms.sum().to(pred.device)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         (grad,) = ctx.saved_tensors
         return (grad * g.to(grad.device)).to(ctx.src_device), None, None, None

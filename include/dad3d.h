@@ -135,8 +135,10 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
 /* dL/d[betas | pose feature] = dL/d(v_posed) . basis^T: the transpose of the blend-shape GEMM of flame.py:212-221 (what torch
  * autograd does for the reference's losses, vertices_3d_loss.py:41), a split-K fp32 MFMA kernel + a fixed-order reduction.
  *   grad_posed [B, 3V] (from dad3d_flame_decode_backward)  ->  grad_inputs [B, dad3d_flame_num_chain_inputs(h)]
- * The basis^T pack and the scratch are created by the first dad3d_flame_decode_posed of the handle (of a larger batch):
- * run one step before capturing a graph. */
+ * The basis^T pack and the scratch are created by the first dad3d_flame_decode_posed of the handle (of a larger batch) when
+ * the batch is at most DAD3D_GRAD_INPUTS_MAX_BATCH -- the range the host mirror uses this entry for (above it a library GEMM
+ * is faster) -- and by the first call of this entry otherwise: run one step before capturing a graph. */
+#define DAD3D_GRAD_INPUTS_MAX_BATCH 96
 dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, int batch, float* grad_inputs, void* stream);
 
 /* Per-image half of the same differentiable decode: everything between a params row and the operands of the per-vertex

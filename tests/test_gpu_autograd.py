@@ -302,6 +302,18 @@ def test_fused_loss_argument_errors():
         from dad_3dheads_amd.losses import RegionTables
 
         RegionTables([1.0], [np.array([0, 8])], 8, torch.device("cuda", 0))
+    # first-order gradients of the prediction only: a target that wants one, or a double backward, raises (the reference's
+    # torch graph would give both; silently returning None / zeros would not be the reference's result)
+    from dad_3dheads_amd.losses import _CRITERION_ID, RegionTables, _WeightedPointLoss
+
+    tables = RegionTables([1.0], [np.array([0, 3, 5])], 8, torch.device("cuda", 0))
+    pred = torch.randn((2, 8, 3), device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="detach the target"):
+        _WeightedPointLoss.apply(pred, torch.randn((2, 8, 3), device="cuda", requires_grad=True), tables, _CRITERION_ID["l2"])
+    loss = _WeightedPointLoss.apply(pred, torch.randn((2, 8, 3), device="cuda"), tables, _CRITERION_ID["l2"])
+    (g,) = torch.autograd.grad(loss, pred, create_graph=True)
+    with pytest.raises(RuntimeError):
+        g.sum().backward()
 
 
 def test_grad_inputs_kernel_matches_the_plain_contraction(flame_model, static):

@@ -301,10 +301,10 @@ def test_region_tables_for_the_fused_losses():
     from dad_3dheads_amd.losses import RegionTables
 
     n = 50
-    idx = [np.array([3, 7, 7, 49]), np.array([-1, 0, 3]), np.zeros(0, dtype=np.int64), np.arange(10, 20)]
-    w = [1.0, 0.5, 9.0, 2.0]
+    idx = [np.array([3, 7, 7, 49]), np.array([-1, 0, 3]), np.arange(10, 20)]
+    w = [1.0, 0.5, 2.0]
     t = RegionTables(w, idx, n, torch.device("cpu"))
-    assert t.n_regions == 4 and t.region_ptr.tolist() == [0, 4, 7, 7, 17]
+    assert t.n_regions == 3 and t.region_ptr.tolist() == [0, 4, 7, 17]
     assert t.region_idx.tolist()[:7] == [3, 7, 7, 49, 49, 0, 3]
     ptr, reg, pos = t.vert_ptr.numpy(), t.vert_region.numpy(), t.vert_pos.numpy()
     assert ptr[0] == 0 and ptr[-1] == 17 and (np.diff(ptr) >= 0).all()
@@ -324,3 +324,16 @@ def test_region_tables_for_the_fused_losses():
     assert np.allclose(t.point_weight.numpy(), expect, rtol=1e-6)
     with pytest.raises(IndexError):
         RegionTables([1.0], [np.array([50])], n, torch.device("cpu"))
+    with pytest.raises(ValueError, match="no vertices"):  # the reference's mean over an empty region is NaN: refused
+        RegionTables([1.0, 1.0], [np.array([3]), np.array([], dtype=np.int64)], n, torch.device("cpu"))
+
+
+def test_grad_inputs_batch_limit_is_the_same_on_both_sides_of_the_c_abi():
+    """include/dad3d.h's DAD3D_GRAD_INPUTS_MAX_BATCH (up to which a training forward prepares the hand-written backward GEMM's
+    pack and scratch) is the threshold the host mirror switches to the library GEMM at."""
+    import re
+
+    from dad_3dheads_amd import autograd
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dad3d.h")).read()
+    assert int(re.search(r"#define\s+DAD3D_GRAD_INPUTS_MAX_BATCH\s+(\d+)", text).group(1)) == autograd.GRAD_INPUTS_HIP_MAX_BATCH
