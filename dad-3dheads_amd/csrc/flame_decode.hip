@@ -545,6 +545,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         }
     };
     if ((int)blockIdx.x < a.n_pose_blocks_pad8) {
+        if (DAD3D_ABLATE & 128) return;  // diagnostics: no pose role, no hand-off (results wrong, timing only)
         bystander();
         if ((int)blockIdx.x < a.n_pose_blocks && threadIdx.x < 256) pose_role<JAW_ONLY, CONTIG, DEV_EPOCH>(a, smem);
         return;
@@ -810,7 +811,9 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         // ONE poller per workgroup (240 pollers on one word already cost the memory system something; four per
         // workgroup with a short sleep measurably slowed the pose role they were waiting for), generous sleep
         // between polls; the other feeder waves wait on an LDS flag.
-        if (wave == 4 && lane == 0) {
+        if (DAD3D_ABLATE & 128) {
+            if (wave == 4 && lane == 0) __hip_atomic_store(handoff_flag, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (wave == 4 && lane == 0) {
             const unsigned ticket = dev_epoch ? take_ticket() : 0u;  // epoch_base is back (older than part 2's loads)
             const unsigned target = dev_epoch ? epoch_base + (unsigned)a.batch : a.arrive_target;
             int st = 2;
@@ -828,7 +831,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         while (lds_peek(handoff_flag) == 0) __builtin_amdgcn_s_sleep(4);
         const int ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
         if (trace && lane == 0) trace[14] = wall_clock64();
-        if (ok) {
+        if (DAD3D_ABLATE & 128) {
+        } else if (ok) {
 #pragma unroll
             for (int i = 0; i < kCst; ++i) {
                 const int idx = i * 256 + ht;
