@@ -48,6 +48,9 @@ namespace {
 
 constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
 constexpr int kCacheSc1 = 16;          // buffer-op aux bit: write-through store / L1-bypassing load
+constexpr int kJawFirstVec = 3, kJawVecs = 9;  // float4s [3, 12) of an image's block: all the jaw-only epilogue reads -- and
+                                               // all that crosses the hand-off (a decode workgroup fetches its 64 images' share
+                                               // from the memory side: 9 KB instead of 21 KB, x 240 tiles x B / 64 per launch)
 constexpr int kTicketWord = kSyncWords - 1;  // the per-launch workgroup ticket: 4 KiB away from the arrival counter, so
                                              // its ~270 same-address atomics queue in another L2 channel
 
@@ -478,7 +481,8 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
         if (lane == i) mine = f32x4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.imgc + (size_t)b * kImgConsts, 0, kImgConsts * (int)sizeof(float), 0x00020000);
-    if (lane < kImgConsts / 4)
+    // JAW_ONLY: the decode role's epilogue reads float4s 3..11 of the block and nothing else (see constants_from_joints)
+    if (JAW_ONLY ? (lane >= kJawFirstVec && lane < kJawFirstVec + kJawVecs) : lane < kImgConsts / 4)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine), rsrc, lane * 16, 0, kCacheSc1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (trace && lane == 0) trace[2] = __builtin_readcyclecounter();
@@ -832,6 +836,17 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         const int ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
         if (trace && lane == 0) trace[14] = wall_clock64();
         if (DAD3D_ABLATE & 128) {
+        } else if (ok && JAW_ONLY) {
+            constexpr int kJawTotal = kBlockImages * kJawVecs;
+#pragma unroll
+            for (int i = 0; i < (kJawTotal + 255) / 256; ++i) {
+                const int idx = i * 256 + ht;
+                if (idx < kJawTotal) {
+                    const int at = (idx / kJawVecs) * (kImgConsts / 4) + kJawFirstVec + idx % kJawVecs;
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(imgc_rsrc, at * 16, 0, kCacheSc1);
+                    reinterpret_cast<f32x4*>(imgc)[at] = __builtin_bit_cast(f32x4, v);
+                }
+            }
         } else if (ok) {
 #pragma unroll
             for (int i = 0; i < kCst; ++i) {
