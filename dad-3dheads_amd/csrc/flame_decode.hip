@@ -396,6 +396,10 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x * 4 + wave;
     const bool live = b < a.batch;
+    if (DAD3D_ABLATE & 512) {  // diagnostics: arrivals only
+        if (live && lane == 0) __hip_atomic_fetch_add(a.sync + (DEV_EPOCH ? 4 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     float* jd = smem;                                         // [15][400]
     float* partial = smem + 3 * kNumJoints * 400 + wave * 1152;  // [64 lanes][17] per wave, 16 sums at [1120,1136)
     float* p = a.params + (size_t)min(b, a.batch - 1) * a.lay.n_params;
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         // ONE poller per workgroup (240 pollers on one word already cost the memory system something; four per
         // workgroup with a short sleep measurably slowed the pose role they were waiting for), generous sleep
         // between polls; the other feeder waves wait on an LDS flag.
-        if (DAD3D_ABLATE & 128) {
+        if (DAD3D_ABLATE & (128 | 256)) {  // 256: the pose role runs, nobody consumes its blocks
             if (wave == 4 && lane == 0) __hip_atomic_store(handoff_flag, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if (wave == 4 && lane == 0) {
             const unsigned ticket = dev_epoch ? take_ticket() : 0u;  // epoch_base is back (older than part 2's loads)
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         while (lds_peek(handoff_flag) == 0) __builtin_amdgcn_s_sleep(4);
         const int ok = __builtin_amdgcn_readfirstlane(lds_peek(handoff_flag) == 1 ? 1 : 0);
         if (trace && lane == 0) trace[14] = wall_clock64();
-        if (DAD3D_ABLATE & 128) {
+        if (DAD3D_ABLATE & (128 | 256)) {
         } else if (ok && JAW_ONLY) {
             constexpr int kJawTotal = kBlockImages * kJawVecs;
 #pragma unroll
