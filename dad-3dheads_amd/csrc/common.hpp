@@ -95,7 +95,7 @@ struct DecodeArgs {
     const int* lmk_head;    // [V][2] first landmark slot of a vertex or -1, and the slot chained after it (or -1)
     const int* lmk_next;    // [n_lmk] next slot with the same vertex or -1
     float* imgc;            // [B][kImgConsts] per-image constants: pose role -> decode role hand-off
-    unsigned* sync;         // [0] arrivals (monotonic over launches)  [1] hand-off time-outs (sticky)
+    unsigned* sync;         // [0] arrivals, one per pose workgroup (monotonic over launches)  [1] hand-off time-outs (sticky)
                             // device-epoch launches (graph capture): [4] their arrivals  [5] arrivals of all earlier
                             // such launches (advanced by the kernel)  [kSyncWords-1] launch ticket
     float* verts3d;         // [B,V,3] or null
@@ -110,7 +110,7 @@ struct DecodeArgs {
     int n_betas, max_shape;  // 400, 300
     int betas_contiguous;    // params[0:400] are the betas (shape == 300 and expression == 100)
     int kgroups;
-    unsigned arrive_target;  // host-side epoch: value of sync[0] once every image of this launch has been published
+    unsigned arrive_target;  // host-side epoch: value of sync[0] once every pose workgroup of this launch has arrived
     unsigned spin_limit;
     float image_size;
     unsigned flags;

@@ -397,7 +397,7 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
     const int b = blockIdx.x * 4 + wave;
     const bool live = b < a.batch;
     if (DAD3D_ABLATE & 512) {  // diagnostics: arrivals only
-        if (live && lane == 0) __hip_atomic_fetch_add(a.sync + (DEV_EPOCH ? 4 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(a.sync + (DEV_EPOCH ? 4 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     float* jd = smem;                                         // [15][400]
@@ -490,7 +490,14 @@ __device__ void pose_role(const DecodeArgs& a, float* smem) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine), rsrc, lane * 16, 0, kCacheSc1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (trace && lane == 0) trace[2] = __builtin_readcyclecounter();
-    if (lane == 0) __hip_atomic_fetch_add(a.sync + (DEV_EPOCH ? 4 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE arrival per workgroup. Same-word agent-scope atomics execute one after the other at the memory side, ~12 ns each,
+    // and a pose workgroup keeps its CU until its own has been performed: with one per image a launch of 1024 images had
+    // every CU's first decode workgroup start up to 12 us late (165.7 -> 158.4 us; B = 256 43.45 -> 42.6; B = 64, where the
+    // pose workgroups have CUs of their own, unchanged). Eight words instead of one bought nothing more and made every
+    // poll eight loads. The barrier counts the live waves only (the others have ended); every wave has drained its own
+    // stores above.
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.sync + (DEV_EPOCH ? 4 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (trace && lane == 0) trace[3] = __builtin_readcyclecounter(), trace[13] = wall_clock64();
 }
 
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     auto advance_epoch_if_last = [&](unsigned ticket, unsigned epoch_base) {
         if (ticket == gridDim.x - 1) {
             __hip_atomic_store(a.sync + kTicketWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.sync + 5, epoch_base + (unsigned)a.batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 5, epoch_base + (unsigned)a.n_pose_blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     auto bystander = [&]() {  // a workgroup that does not consume the hand-off: thread 511 (idle in the pose role)
@@ -823,11 +830,11 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
             if (wave == 4 && lane == 0) __hip_atomic_store(handoff_flag, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if (wave == 4 && lane == 0) {
             const unsigned ticket = dev_epoch ? take_ticket() : 0u;  // epoch_base is back (older than part 2's loads)
-            const unsigned target = dev_epoch ? epoch_base + (unsigned)a.batch : a.arrive_target;
+            const unsigned target = dev_epoch ? epoch_base + (unsigned)a.n_pose_blocks : a.arrive_target;
             int st = 2;
             for (unsigned spin = 0; spin < a.spin_limit; ++spin) {
                 const unsigned seen = __hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(seen - target) >= 0) {  // every image's pose wave arrives once per launch
+                if ((int)(seen - target) >= 0) {  // every pose workgroup arrives once per launch
                     st = 1;
                     break;
                 }
