@@ -573,6 +573,7 @@ constexpr unsigned kSplit1 = DAD3D_SPLIT1, kSplit2 = 4 * DAD3D_SPLIT1;  // tile 
 constexpr int kLaneShift = DAD3D_LANE_SHIFT;  // a class-c triangle (box area <= 2^(c+1)) gets 2^max(c - kLaneShift, 0) lanes: <= 2^(kLaneShift+1) tests per lane
 constexpr int kMaxSubs = 16;
 constexpr int kQueueBuckets = 64;
+constexpr int kTicketStride = 64;    // words between two images' block counters
 constexpr unsigned kNoTri = 0xFFFFFFFFu;
 constexpr unsigned kIdMask = 0x0FFFFFFFu;  // list entry = triangle | class << 28
 
@@ -596,7 +597,8 @@ struct RasterScratch {
     unsigned* counts;   // [2][B * ntiles]  triangles in a tile list, then the sum of their box areas inside the tile;
                         //                  zero between launches (the queue kernel resets them)
     unsigned* lists;    // [B * ntiles][ntri]   triangle | area class within the tile << 28
-    unsigned* qhdr;     // [0] work items in the queue  [1] next item to hand out  [2] geometry blocks finished
+    unsigned* qhdr;     // [0] work items in the queue  [1] next item to hand out  [2] images whose geometry blocks have all finished
+    unsigned* img_done; // [B][kTicketStride]  geometry blocks of an image that have finished (word 0 of each 256-byte slot)
     uint2* queue;       // [16 * B * ntiles]  .x = tile index | split level << 24 | part << 26, .y = list length
     int tiles_x, tiles_y;
 };
@@ -805,12 +807,25 @@ __global__ __launch_bounds__(kGeoThreads) void tri_geometry_kernel(MeshDev m, co
     // stream: measured 195 us): the counter updates are agent-scope atomics, performed at the coherence point; every
     // thread drains its own (vmcnt) before the barrier, the ticket is taken after it, and the last block reads the
     // counters with agent-scope atomic loads.
+    // The ticket is taken in two levels: same-word agent-scope atomics are performed one after the other at the memory side
+    // (~12 ns each), so one word for all the launch's blocks made the last of 256 blocks that finish together wait ~3 us
+    // for its answer. An image's blocks count on a word of their own (256 bytes from the next image's: another channel), the
+    // last of them counts the image.
     __shared__ unsigned s_ticket;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_ticket = atomicAdd(&sc.qhdr[2], 1u);
+    if (tid == 0) {
+        unsigned t = atomicAdd(&sc.img_done[b * kTicketStride], 1u);
+        if (t == gridDim.x - 1) {
+            sc.img_done[b * kTicketStride] = 0;  // for the next launch (nobody else touches the word any more)
+            t = atomicAdd(&sc.qhdr[2], 1u) == gridDim.y - 1 ? 1u : 0u;
+        } else {
+            t = 0u;
+        }
+        s_ticket = t;
+    }
     __syncthreads();
-    if (s_ticket != gridDim.x * gridDim.y - 1) return;
+    if (!s_ticket) return;
     build_work_queue(sc, (int)gridDim.y * ntiles, cnt, tid);  // cnt[]: this block's LDS counters are dead by now
     if (tid == 0) sc.qhdr[2] = 0;
 }
@@ -1414,13 +1429,14 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int tiles_of(int extent) { return (extent + kTile - 1) / kTile; }
 struct ScratchLayout {
-    size_t rec, counts, qhdr, queue, lists, total;
+    size_t rec, counts, qhdr, img_done, queue, lists, total;
     ScratchLayout(const MeshDev& m, int batch, int h, int w) {
         const size_t nt = m.ntri, nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
         rec = 0;
         counts = align256(rec + batch * nt * sizeof(float3u));
         qhdr = align256(counts + 2 * nlists * sizeof(unsigned));
-        queue = align256(qhdr + 4 * sizeof(unsigned));
+        img_done = align256(qhdr + 4 * sizeof(unsigned));
+        queue = align256(img_done + (size_t)batch * kTicketStride * sizeof(unsigned));
         lists = align256(queue + nlists * kMaxSubs * sizeof(uint2));
         total = align256(lists + nlists * nt * sizeof(unsigned));
     }
@@ -1473,6 +1489,7 @@ dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc_all, v
     char* base = static_cast<char*>(scratch);
     RasterScratch sc{reinterpret_cast<float3u*>(base + lay.rec),   reinterpret_cast<unsigned*>(base + lay.counts),
                      reinterpret_cast<unsigned*>(base + lay.lists), reinterpret_cast<unsigned*>(base + lay.qhdr),
+                     reinterpret_cast<unsigned*>(base + lay.img_done),
                      reinterpret_cast<uint2*>(base + lay.queue),    tiles_of(w), tiles_of(h)};
     const int ntiles = sc.tiles_x * sc.tiles_y;
     {
