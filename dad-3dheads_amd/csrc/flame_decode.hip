@@ -3,7 +3,8 @@
 //   pose role   (the first ceil(B/4) workgroups, one 64-lane wave per image)
 //       params row -> joints J = J0 + Jdirs.betas, Rodrigues per joint, kinematic chain A_j, 6-DoF rotation R,
 //       scale/translation -> an 84-float per-image constant block, published write-through (sc1) to HBM,
-//       then one agent-scope arrival per image on a monotonic counter.
+//       then ONE agent-scope arrival per workgroup on a monotonic counter (and only float4s 3..11 of the block in the
+//       jaw-only layout: all its epilogue reads).
 //       Restates FLAMELayer.forward's setup (model_training/model/flame.py:191-210), smplx.lbs steps 2,3,5
 //        and rot_mat_from_6dof (model_training/model/utils.py:92-101).
 //
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
 #undef DAD3D_WRITE_PART
         stamp(3);
         // ---- hand-off from the pose role (the mma waves are still multiplying the last, largest part) ------
-        // One lane polls the arrival counter (relaxed, agent scope) until every image of this launch has been
+        // One lane polls the arrival counter (relaxed, agent scope) until every pose workgroup of this launch has
         // published; the block is then fetched with sc1 loads (served by L2/memory, never a stale L1 line).
         constexpr int kVec = kBlockImages * kImgConsts / 4;  // float4s of this block's per-image constants
         constexpr int kCst = (kVec + 255) / 256;
