@@ -420,7 +420,7 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     const bool device_epoch = capture != hipStreamCaptureStatusNone;
     da.arrive_target = h->arrive_total + (unsigned)da.n_pose_blocks;  // every pose workgroup arrives once per launch
     da.spin_limit = 1u << 20;
-#ifdef DAD3D_DIAG_SPIN_ENV  // diagnostics builds only (tools/attic): hand-off spin limit from the environment
+#ifdef DAD3D_DIAG_SPIN_ENV  // diagnostics builds only (tools/build_variant.sh): hand-off spin limit from the environment
     if (const char* e = getenv("DAD3D_SPIN_LIMIT")) da.spin_limit = (unsigned)atoi(e);
 #endif
     da.image_size = h->image_size;
