@@ -275,7 +275,7 @@ def observed_shader_clock_mhz(lib, handle, call, dev):
     from dad_3dheads_amd import _lib
 
     try:
-        n_rows = (240 * 8 + 16 * 4) * 32
+        n_rows = 4096 * 32  # >= (workgroups x 8 waves) x 32 stamps of either decode kernel
         trace = torch.zeros(n_rows, dtype=torch.int64, device=dev)
         for _ in range(50):  # clocks as in the timed region
             lib.dad3d_flame_decode(*call)

@@ -41,11 +41,13 @@ using namespace dad3d;
 struct FlameConsts {
     int device = 0;
     float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
+    float* d_bpack_pipe = nullptr;  // basis of the 20-vertex tiles + jaw-joint columns (flame_decode_pipe.hip); null: model not covered
+    int n_tiles_pipe = 0;
     float* d_gpack = nullptr;  // basis^T in MFMA fragment order for dad3d_flame_grad_inputs: built by the first training forward
     std::mutex gpack_mutex;
     ~FlameConsts() {
         DeviceGuard guard(device);
-        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8, (void*)d_gpack})
+        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8, (void*)d_gpack, (void*)d_bpack_pipe})
             if (p) (void)hipFree(p);
     }
 };
@@ -62,6 +64,7 @@ struct dad3d_flame {
     float image_size = 256.f;
     std::shared_ptr<FlameConsts> c;
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
+    float4* d_vtab = nullptr;  // [V] {W, w_jaw, first landmark slot, slot chained after it}: per handle (the landmark list is)
     float* d_bwd_partials = nullptr;  // [cap][kBackwardMaxSplit][72] scratch of dad3d_flame_decode_backward
     int bwd_cap = 0;
     float* d_grad_partials = nullptr;  // [slices][padded batch][kGradRows] scratch of dad3d_flame_grad_inputs
@@ -76,6 +79,35 @@ struct dad3d_flame {
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
 };
+
+// Which decode kernel a launch takes: DAD3D_DECODE_KERNEL=v1 forces the two-role kernel of rounds 1-3, =pipe the pipelined
+// single-role kernel whenever the model is covered (diagnostics / A-B timing); default: pipe above 16 images.
+static int decode_kernel_choice() {
+    static const int choice = [] {
+        const char* e = getenv("DAD3D_DECODE_KERNEL");
+        if (!e) return 0;
+        return (e[0] == 'v' && e[1] == '1') ? 1 : (e[0] == 'p') ? 2 : 0;
+    }();
+    return choice;
+}
+
+// the per-vertex table of the pipelined kernel: skinning weights from the model, landmark slots from the handle's list
+static dad3d_status upload_vtab(dad3d_flame* h, const std::vector<int>& head2) {
+    if (!h->c->d_bpack_pipe) return DAD3D_OK;
+    std::vector<float> w8((size_t)h->n_verts * 8);
+    DAD3D_HIP_TRY(hipMemcpy(w8.data(), h->c->d_w8, w8.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float4> vt(h->n_verts);
+    for (int v = 0; v < h->n_verts; ++v) {
+        const float* w = &w8[(size_t)v * 8];
+        int hd = head2[(size_t)v * 2], nx = head2[(size_t)v * 2 + 1];
+        float fh, fn;
+        memcpy(&fh, &hd, 4), memcpy(&fn, &nx, 4);
+        vt[v] = float4{w[5] + w[2], w[2], fh, fn};  // W = (w0 + w1 + w3 + w4) + w_jaw
+    }
+    if (!h->d_vtab) DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_vtab), vt.size() * sizeof(float4)));
+    DAD3D_HIP_TRY(hipMemcpy(h->d_vtab, vt.data(), vt.size() * sizeof(float4), hipMemcpyHostToDevice));
+    return DAD3D_OK;
+}
 
 static int grad_chunks(const dad3d_flame* h) { return (h->n_verts * 3 + kGradChunk - 1) / kGradChunk; }
 
@@ -274,13 +306,47 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
     }
     std::vector<int> head((size_t)V * 2, -1);  // [V][2]: first landmark slot of the vertex, the slot after it
 
+    // ---- the pipelined single-role kernel (flame_decode_pipe.hip): jaw-only models with the dad_3dnet.yaml params layout.
+    // Tiles of 20 vertices; columns 60..62 of every tile carry the jaw joint J_jaw = J0_jaw + Jdirs_jaw . betas (rows of the pose
+    // feature contribute nothing to a joint: smplx regresses the joints from v_shaped), column 63 is zero.
+    const bool pipe_ok = jaw_only && c->jaw == 3 && c->shape == 300 && c->expression == 100 && L.jaw_off == 400 && L.rot_off == 403 &&
+                         L.trans_off == 409 && L.scale_off == 412 && L.n_params == 413 && h->kgroups == kPipeKGroups;
+    std::vector<float> bpack_pipe;
+    const int n_tiles_pipe = (V + kPipeTileVerts - 1) / kPipeTileVerts;
+    if (pipe_ok) {
+        bpack_pipe.assign((size_t)n_tiles_pipe * kPipeKGroups * 4 * 64 * 4, 0.0f);
+        for (int t = 0; t < n_tiles_pipe; ++t)
+            for (int g = 0; g < kPipeKGroups; ++g)
+                for (int w = 0; w < 4; ++w)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int col = w * 16 + (lane & 15);
+                        float* dst = &bpack_pipe[((((size_t)t * kPipeKGroups + g) * 4 + w) * 64 + lane) * 4];
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = 16 * g + 4 * (lane >> 4) + i;
+                            if (k >= k_used) continue;
+                            if (col < 3 * kPipeTileVerts) {
+                                const int v = t * kPipeTileVerts + col / 3;
+                                if (v < V) dst[i] = basis(k, v, col % 3);
+                            } else if (col < 3 * kPipeTileVerts + 3) {
+                                const int o = 2 * 3 + (col - 3 * kPipeTileVerts);  // joint 2 = jaw
+                                dst[i] = k < NB ? jdirs[(size_t)o * NB + k] : (k == NB + h->n_pose_feats ? j0[o] : 0.0f);
+                            }
+                        }
+                    }
+    }
+
     dad3d_status st;
     h->c = std::make_shared<FlameConsts>();
     h->c->device = device;
+    h->c->n_tiles_pipe = n_tiles_pipe;
+    if (pipe_ok && (st = upload(&h->c->d_bpack_pipe, bpack_pipe))) {
+        dad3d_flame_destroy(h.release());
+        return st;
+    }
     if ((st = upload(&h->c->d_bpack, bpack)) || (st = upload(&h->c->d_jdirs, jdirs)) || (st = upload(&h->c->d_j0, j0)) ||
         (st = upload(&h->c->d_w8, w8)) || (st = upload(&h->d_lmk_head, head)) ||
         (st = upload(&h->d_lmk_next, std::vector<int>())) || (st = upload(&h->d_sync, std::vector<unsigned>(kSyncWords, 0u))) ||
-        (st = flame_reserve(h.get(), 1))) {
+        (st = flame_reserve(h.get(), 1)) || (st = upload_vtab(h.get(), head))) {
         dad3d_flame_destroy(h.release());
         return st;
     }
@@ -292,7 +358,7 @@ void dad3d_flame_destroy(dad3d_flame* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials,
-                    (void*)h->d_grad_partials})
+                    (void*)h->d_grad_partials, (void*)h->d_vtab})
         if (p) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
@@ -306,6 +372,7 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", parent->device);
     std::unique_ptr<dad3d_flame> h(new dad3d_flame(*parent));  // layout, tiling, shared constants
     h->d_lmk_head = h->d_lmk_next = nullptr;
+    h->d_vtab = nullptr;
     h->d_imgc = nullptr;
     h->d_sync = nullptr;
     h->d_bwd_partials = nullptr;
@@ -328,6 +395,14 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
         if (st == DAD3D_OK) set_error("dad3d_flame_fork: device allocation or copy failed");
         dad3d_flame_destroy(h.release());
         return st == DAD3D_OK ? DAD3D_E_HIP : st;
+    }
+    if (parent->d_vtab) {
+        if (hipMalloc(reinterpret_cast<void**>(&h->d_vtab), nv * sizeof(float4)) != hipSuccess ||
+            hipMemcpy(h->d_vtab, parent->d_vtab, nv * sizeof(float4), hipMemcpyDeviceToDevice) != hipSuccess) {
+            set_error("dad3d_flame_fork: device allocation or copy failed");
+            dad3d_flame_destroy(h.release());
+            return DAD3D_E_HIP;
+        }
     }
     *out = h.release();
     return DAD3D_OK;
@@ -358,7 +433,7 @@ dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n
     (void)hipFree(h->d_lmk_next);
     h->d_lmk_next = d_next;
     h->n_lmk = n;
-    return DAD3D_OK;
+    return upload_vtab(h, head2);
 }
 
 static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
@@ -377,6 +452,37 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     if (posed && batch <= DAD3D_GRAD_INPUTS_MAX_BATCH && h->n_betas + 36 <= kGradRows) {
         dad3d_status st = grad_inputs_prepare(h, batch, s);
         if (st) return st;
+    }
+    // The pipelined single-role kernel (flame_decode_pipe.hip): inference outputs of a covered model. It walks the batch in
+    // half-blocks of 32 images; a launch of 33..64 images is the one shape where the two-role kernel's single 64-image pass -- as
+    // long as the basis takes to stream in -- is still ahead (12.8 against 14.3 us at 64; 8.2 / 9.3 / 18.2 / 38.5 / 137 / 268 us
+    // against 8.3 / 11.5 / 22.4 / 42.5 / 158 / 325 at 1 / 32 / 96 / 256 / 1024 / 2048: profiles/r04_ab_decode.txt).
+    const int choice = decode_kernel_choice();
+    const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
+                             (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
+    if (pipe_covers && choice != 1 && (batch <= kPipeHalf || batch > 2 * kPipeHalf || choice == 2)) {
+        PipeArgs pa{};
+        pa.params = params;
+        pa.bpack = h->c->d_bpack_pipe;
+        pa.vtab = h->d_vtab;
+        pa.lmk_next = h->d_lmk_next;
+        pa.verts3d = verts3d;
+        pa.proj = proj;
+        pa.lmk_xy = lmk_xy;
+        pa.lmk_px = lmk_px;
+        pa.trace = h->d_trace;
+        pa.n_params = h->lay.n_params;
+        pa.batch = batch;
+        pa.n_half = (batch + kPipeHalf - 1) / kPipeHalf;
+        pa.n_tiles = h->c->n_tiles_pipe;
+        pa.n_verts = h->n_verts;
+        pa.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
+        pa.image_size = h->image_size;
+        pa.flags = flags & 0xFFu;
+        dad3d_status st = launch_flame_decode_pipe(pa, s);
+        if (st) return st;
+        if (h->profiling) ++h->prof_launches;
+        return DAD3D_OK;
     }
     const int nbb = (batch + kBlockImages - 1) / kBlockImages;
     if (nbb > h->cap_nbb) {

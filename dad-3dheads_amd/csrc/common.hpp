@@ -120,6 +120,31 @@ struct DecodeArgs {
 
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s);
 
+// Single-role, persistent, software-pipelined decode (flame_decode_pipe.hip, round 4): one workgroup per tile of 20 vertices
+// walks the batch in half-blocks of 32 images. No pose role, no hand-off: the jaw joint rides the GEMM as columns 60..62 of
+// every tile (J_jaw = J0_jaw + Jdirs_jaw . betas is linear in the betas), the other per-image constants come straight from
+// the params row. Jaw-only models with the dad_3dnet.yaml params layout; inference outputs only.
+constexpr int kPipeTileVerts = 20;  // 60 basis columns + 3 jaw-joint columns + 1 zero pad = 64
+constexpr int kPipeHalf = 32;       // images per pipeline stage: 2 MFMA row blocks of 16
+constexpr int kPipeKGroups = 26;    // K = 400 betas + 9 jaw pose features + the template row -> 416
+struct PipeArgs {
+    float* params;           // [B,P] (tz written when DAD3D_MUTATE_PARAMS)
+    const float* bpack;      // [n_tiles][26][4 waves][64 lanes][4]: basis of the 20-vertex tiles + the jaw-joint columns
+    const float4* vtab;      // [V] {W = sum of the five skinning weights, w_jaw, first landmark slot, slot chained after it} (the
+                             //      last two as int bits; -1 = none)
+    const int* lmk_next;     // [n_lmk] next slot with the same vertex or -1
+    float* verts3d;          // [B,V,3] or null
+    float* proj;             // [B,V,2|3] or null
+    float* lmk_xy;           // [B,n_lmk,2] or null
+    int32_t* lmk_px;         // [B,n_lmk,2] or null
+    unsigned long long* trace;  // diagnostics: [n_tiles][8 waves][32] stamps, or null
+    int n_params, batch, n_half, n_tiles, n_verts, n_lmk;
+    float image_size;
+    unsigned flags;
+};
+dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s);
+size_t flame_decode_pipe_lds_bytes();
+
 // Backward of the per-vertex half of the decode (flame_backward.hip). Per-image constants, natural joint order:
 //   [0,60) A_j rows 0..2 of the relative transforms (j = 0..4, 12 floats each)   [60,69) G row-major   [69] s   [70,72) tx ty
 constexpr int kBackwardConsts = 72;

@@ -29,6 +29,7 @@
 // group is permuted (lane group q takes rows 4q..4q+3) so that one conflict-free ds_read_b128 delivers a
 // lane's A operand for four consecutive MFMAs straight from the row-major image.
 #include "common.hpp"
+#include "flame_math.hpp"  // rodrigues_minus_identity, normalize3
 
 #ifndef DAD3D_ABLATE  // diagnostics builds only (tools/ablate.sh); 0 in the product
 #define DAD3D_ABLATE 0
@@ -78,43 +79,9 @@ __device__ __forceinline__ void rodrigues(const float r[3], float R[9]) {
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * K[i] + c1 * KK[i];
 }
 
-// R - I of smplx.lbs.batch_rodrigues for one joint, written for the decode role's start-up path (every workgroup needs the
-// pose feature of its 64 images before the GEMM's last group): K.K = a a^T - |a|^2 I, so R - I = sin*K + (1-cos)*(a a^T - |a|^2 I)
-// without forming 1 + x - 1 (the reference's own rounding of that is 6e-8); 1/angle from v_rsq_f32 (1 ulp). ~90 VALU
-// instructions instead of ~300 (correctly rounded sqrt and three divisions): an instruction of a wave that shares its SIMD
-// with a streaming mma wave costs the matrix pipe ~8 cycles.
-__device__ __forceinline__ void rodrigues_minus_identity(const float r[3], float D[9]) {
-    const float ex = r[0] + 1e-8f, ey = r[1] + 1e-8f, ez = r[2] + 1e-8f;
-    const float n2 = ex * ex + ey * ey + ez * ez;
-    const float inv = __builtin_amdgcn_rsqf(n2);
-    const float angle = n2 * inv;
-    const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
-    float s, c;
-    sincosf(angle, &s, &c);
-    const float c1 = 1.0f - c;
-    const float aa = x * x + y * y + z * z;
-    const float cxy = c1 * (x * y), cxz = c1 * (x * z), cyz = c1 * (y * z);
-    D[0] = c1 * (x * x - aa);
-    D[1] = cxy - s * z;
-    D[2] = cxz + s * y;
-    D[3] = cxy + s * z;
-    D[4] = c1 * (y * y - aa);
-    D[5] = cyz - s * x;
-    D[6] = cxz - s * y;
-    D[7] = cyz + s * x;
-    D[8] = c1 * (z * z - aa);
-}
-
 __device__ __forceinline__ void identity3(float R[9]) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
-}
-
-__device__ __forceinline__ void normalize3(float v[3]) {  // F.normalize(eps=1e-12)
-    const float n = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
-    v[0] /= n;
-    v[1] /= n;
-    v[2] /= n;
 }
 
 // full_pose = [global 0 | neck | jaw | eyeballs] (flame.py:201-208): the up-to-12 pose inputs of one image
@@ -908,6 +875,13 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
     // POSED (training callers only, its own instantiation: the inference kernel does not carry the branch)
     float* const ps_base = POSED ? a.posed + ((size_t)wimg * a.n_verts + v0) * 3 : nullptr;
     const unsigned nv = (unsigned)a.n_verts, nl = (unsigned)a.n_lmk;
+#ifndef DAD3D_NT_STORES  // 1: the vertex outputs leave as non-temporal stores (they stream through the L2 instead of piling up dirty
+#define DAD3D_NT_STORES 0  // lines for the end-of-kernel write-back); measured in round 4, see profiles/r04_kernel_log.md
+#endif
+    auto st = [](float* p, float v) {
+        if (DAD3D_NT_STORES) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    };
     auto put_landmark = [&](unsigned li, int slot, float ox, float oy) {
         const unsigned off = (li * nl + (unsigned)slot) * 2u;
         if (lx_base) *reinterpret_cast<float2*>(lx_base + off) = float2{ox, oy};
@@ -983,15 +957,15 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
         }
         if (v3_base) {
             float* d = v3_base + lv * 3u;
-            d[0] = zero_rot ? px : rx;
-            d[1] = zero_rot ? py : ry;
-            d[2] = zero_rot ? pz : rz;
+            st(d, zero_rot ? px : rx);
+            st(d + 1, zero_rot ? py : ry);
+            st(d + 2, zero_rot ? pz : rz);
         }
         if (pj_base) {
             float* d = pj_base + lv * (unsigned)pc;
-            d[0] = ox;
-            d[1] = oy;
-            if (!to2d) d[2] = zsign * ((rz * sc + 0.0f + 1.0f) / 2.0f * a.image_size);
+            st(d, ox);
+            st(d + 1, oy);
+            if (!to2d) st(d + 2, zsign * ((rz * sc + 0.0f + 1.0f) / 2.0f * a.image_size));
         }
         if (lhead >= 0) {
             put_landmark((unsigned)li, lhead, ox, oy);

@@ -1,0 +1,482 @@
+// FLAME / HeadMesh decode for gfx950 (MI355X), round 4: ONE role, persistent workgroups, a software pipeline over the batch.
+//
+// Why (profiles/r04_kernel_log.md section 1, tools/coissue_probe.hip): v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate and
+// every VALU instruction issued on its SIMD -- by the multiplying wave itself or by a second wave; fp32, integer, packed or a
+// plain move alike -- costs the matrix pipe ~6 cycles (transcendentals ~9). A second wave's VALU work is moreover THROTTLED
+// beside a streaming MFMA wave (~0.3 instructions per MFMA issued), while its LDS and memory instructions get ~1 slot per MFMA
+// and cost the matrix pipe nothing. So: arithmetic belongs in the multiplying wave's own stream, data movement in a second
+// wave, and a block of 64 images x 64 columns costs its SIMD 13.3 k cycles of MFMA + ~6 x (VALU instructions) + whatever
+// nothing overlaps. The two-role kernel of rounds 1-3 (flame_decode.hip) spends ~1.2 k non-MFMA instructions per SIMD and
+// block and overlaps nothing: 24.4 k cycles per block. This kernel:
+//
+//   * one workgroup per tile of 20 vertices (252 tiles) walks the whole batch in HALF-BLOCKS of 32 images. Its four "mma"
+//     waves (one per SIMD) keep their basis slice (26 KB each) in registers for the whole launch; per half-block they run
+//     ds_read_b128 + MFMA, park the accumulators in LDS, meet at ONE s_barrier and finish their share of the half-block
+//     (8 images x 20 vertices each) themselves. Its four "stager" waves do nothing but move the params rows of half-block h + 1
+//     into the other LDS image while half-block h multiplies (global loads a phase ahead, ds_write_b128, the same barrier).
+//   * no pose role and no hand-off: the only joint the jaw-only skinning needs, J_jaw = J0 + Jdirs.betas, is linear in the
+//     betas and rides the GEMM as columns 60..62 of every tile. With R_j = I for every joint but the jaw the reference's
+//     T.[v;1] = sum_j w_j A_j [v;1] collapses to  W v + w_jaw (R_jaw - I)(v - J_jaw)  (W = sum of the weights): the
+//     translations of the other joints and the jaw's (J_jaw - J_neck) + (J_neck - J_root) + J_root chain cancel to fp32
+//     rounding (<= 2e-8 in model units; bar 5e-6, north star 1e-4). The other per-image constants (Rodrigues of the jaw,
+//     6-DoF rotation, scale, translation) are computed by the mma waves for 128 images at a time -- the first round inside
+//     the start-up bubble -- into an LDS ring.
+//   * epilogue with the per-image constants in REGISTERS: lane (image i of the wave's 8, vertex group u) holds the image's 24
+//     constants for the half-block and the weights / landmark slots of its <= 3 vertices for the launch, so a (vertex, image)
+//     costs 3 LDS reads + ~30 VALU and leaves as one 12-byte and one 8-byte store (eight lanes = eight consecutive vertices
+//     of one image: 96 / 64 contiguous bytes). ~110 VALU instructions per mma wave and half-block, ~220 per SIMD and block
+//     instead of ~860.
+//
+// Reference arithmetic: model_training/model/flame.py:191-228 (betas, pose feature, lbs, +MESH_OFFSET_Z, 6-DoF rotation),
+// smplx.lbs steps 1-6, model_training/model/utils.py:92-101, model_training/head_mesh.py:39-45,
+// demo_utils.py:42-46 (int truncation of the landmark pixels).
+// No implicit fp contraction in this translation unit: the epilogue and the constants code are inlined at several places (first
+// half-block, steady state, last half-block) and every copy has to round identically -- duplicate params rows give bit-identical
+// outputs whichever half-block they land in (tests/test_gpu_decode.py). The fused multiply-adds are written out.
+#pragma clang fp contract(off)
+#include "common.hpp"
+#include "flame_math.hpp"
+
+#ifndef DAD3D_PIPE_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no vertex stores, 2 = no epilogue in the GEMM,
+#define DAD3D_PIPE_ABLATE 0  // 4 = no constants rounds after the first. Results wrong, timing meaningful. 0 in the product
+#endif
+#ifndef DAD3D_PIPE_NT  // 1 = non-temporal vertex stores: the outputs (105 KB per image) stream through the L2 instead of evicting the
+#define DAD3D_PIPE_NT 1  // basis and piling up dirty lines for the end-of-kernel write-back: 21.95 / 38.2 against 23.5 / 40.7 us at B = 128 / 256
+#endif
+#ifndef DAD3D_PIPE_STAGER_PRIO  // s_setprio of the stager waves (the mma waves stay at 0). Their instructions are few and every
+#define DAD3D_PIPE_STAGER_PRIO 0  // one of them sits on a latency chain -- but priority 1 measured slower at every size (14.9 / 23.7 / 40.5 / 139.2
+                                  // against 14.0 / 22.6 / 39.5 / 138.4 us at B = 64 / 128 / 256 / 1024, same call; 3: as 1)
+#endif
+
+namespace dad3d {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B access to a 4-byte aligned address
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));  // 12 B store
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8 B store to a 4-byte aligned address
+typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef __attribute__((address_space(3))) int lds_int;
+
+constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
+constexpr int KG = kPipeKGroups;       // MFMA groups of 16 k
+constexpr int HB = kPipeHalf;          // images per half-block
+constexpr int TV = kPipeTileVerts;     // vertices per tile
+constexpr int kNumBeta = 400;
+constexpr int kJawCol = 3 * TV;        // columns 60..62 of a tile: the jaw joint
+constexpr int LD = 424;                // A image row stride (floats): LD / 4 odd -> conflict-free ds_read_b128 of the fragments
+constexpr int OS = 76;                 // accumulator tile row stride: 76 = 12 (mod 32) -> the epilogue's (image, vertex) reads
+                                       // of a half-wave hit 32 different banks (12 i covers the multiples of 4, 3 u the rest)
+constexpr int CS = 24;                 // per-image constants: D 9 | G 9 | s tx ty | 3 pad
+constexpr int kRound = 128;            // images per constants round: 4 mma waves x 32 lanes; ring of two rounds
+struct Lds {
+    static constexpr int a_off = 0;                          // [2][HB][LD]      params rows, double buffered
+    static constexpr int o_off = a_off + 2 * HB * LD;        // [2][HB][OS]      accumulators, double buffered
+    static constexpr int c_off = o_off + 2 * HB * OS;        // [2][kRound][CS]  per-image constants, two rounds
+    static constexpr int y_off = c_off + 2 * kRound * CS;    // [4] arrival words of the first A image's three parts
+    static constexpr int total = y_off + 4;
+    static_assert(total * 4 <= 160 * 1024, "LDS budget of one CU");
+};
+
+__device__ __forceinline__ int lds_peek(lds_int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wait_ge(lds_int* p, int target) {
+    while (lds_peek(p) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void arrive(lds_int* p, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have completed
+    if (lane == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// workgroup barrier that does NOT drain the wave's outstanding global loads / stores (__syncthreads would: vmcnt(0)); the
+// stagers keep the next A image in flight across it, the mma waves their stores
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, f32x2{b, b}, c); }
+
+// ---- the GEMM of one half-block on one mma wave: acc[m] += A[16 m .. 16 m + 16][k] * basis[k][16 columns] --------------------
+// Groups [G0, G1) of 16 k; `af` carries the prefetched A fragments from one call to the next. FIRST: the launch's first
+// half-block -- the A image arrives in three parts (arrival words) and the basis slice is still on its way into the registers: the
+// first half-block of a launch runs at the pace of the basis stream (25.6 MB through every CU's share of the memory system),
+// not at the pace of the matrix pipe.
+// hook(G) runs between the MFMAs of group G and those of group G + 1: the previous half-block's epilogue rides here in pieces,
+// so that its LDS round trips hide and its stores leave spread over the GEMM instead of as one burst of every CU.
+template <bool FIRST, int G0, int G1, class Hook>
+__device__ __forceinline__ void gemm_groups(const float* afrag, const float4 (&bq)[KG], f32x4 (&acc)[2], float4 (&af)[2], lds_int* parts,
+                                            Hook&& hook) {
+    float4 an[2] = {};
+    if (G0 == 0) {
+        if (FIRST) wait_ge(parts, 4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
+    }
+#pragma unroll
+    for (int G = G0; G < G1; ++G) {
+        if (FIRST && G + 1 == 8) wait_ge(parts + 1, 4);
+        if (FIRST && G + 1 == 16) wait_ge(parts + 2, 5);  // four stagers and the mma wave that wrote the tail rows
+        if (G + 1 < KG) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[m] = an[m];
+        hook(G);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace
+
+// Barrier protocol (every wave of the workgroup executes exactly 1 + H phase barriers):
+//   B0      after the mma waves have written constants round 0 (wave 0 also the tail rows of A(0), inside the first GEMM)
+//   A(h)    after the mma waves have parked half-block h, the stagers have written A(h + 1) (and its tail rows)
+// Between A(h - 1) and A(h): mma waves [write a constants round,] multiply half-block h out of image h & 1 -- finishing half-block
+// h - 1 (accumulator tile (h - 1) & 1, constants already in registers) in the gaps -- park it in tile h & 1 and load its constants
+// into registers; stagers write image (h + 1) & 1 -- last read by GEMM(h - 1) -- and request the rows of half-block h + 2.
+// TO2D: `proj` is [B,V,2] (head_mesh.py:44-45 `to_2d`), else [B,V,3]. DAD3D_ZERO_ROTATION launches take the two-role kernel.
+template <bool TO2D>
+__global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* abuf = smem + Lds::a_off;
+    float* otile = smem + Lds::o_off;
+    float* cst = smem + Lds::c_off;
+    lds_int* parts = (lds_int*)(smem + Lds::y_off);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, v0 = tile * TV;
+    const int H = a.n_half, B = a.batch, P = a.n_params;
+    unsigned long long* trace = a.trace ? a.trace + ((size_t)tile * 8 + wave) * 32 : nullptr;
+    auto stamp = [&](int slot) {
+        if (trace && lane == 0) trace[slot] = __builtin_readcyclecounter();
+    };
+    if (trace && lane == 0) trace[12] = wall_clock64();
+    stamp(0);
+    if (tid < 4) __hip_atomic_store(parts + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+    if (wave >= 4) {
+        // =============================================== stager waves =====================================================
+        if (DAD3D_PIPE_STAGER_PRIO) __builtin_amdgcn_s_setprio(DAD3D_PIPE_STAGER_PRIO);
+        const int fw = wave - 4, ht = tid - 256;
+        // thread copies the float4s (row srow, 32 j + 4 c4), j = 0..12, of the half-block's 32 params rows (params[:, 0:400] are
+        // the betas: shape 300 + expression 100, flame.py:192-200 with nothing to pad). Rows are 4-byte aligned (413 floats).
+        const int srow = ht >> 3, c4 = ht & 7;
+        float4 pre[13];  // the thread's share of the NEXT A image, requested a phase ahead
+        auto load_a = [&](int hb) {
+            const float* prow = a.params + (size_t)min(hb * HB + srow, B - 1) * P;  // rows past the batch re-read its last row
+#pragma unroll
+            for (int jj = 0; jj < 13; ++jj) {
+                const int kk = (32 * jj + 28 < kNumBeta) ? 32 * jj + 4 * c4 : min(32 * jj + 4 * c4, kNumBeta - 4);
+                const f4u v = *reinterpret_cast<const f4u*>(prow + kk);
+                pre[jj] = float4{v.x, v.y, v.z, v.w};
+            }
+        };
+        auto write_a = [&](int hb, int j0, int j1) {  // slabs [j0, j1) of 32 k; MFMA groups [0,8) [8,16) [16,26) = slabs [0,4) [4,8) [8,13)
+            float* dst = abuf + (hb & 1) * (HB * LD) + srow * LD + 4 * c4;
+#pragma unroll
+            for (int jj = 0; jj < 13; ++jj)
+                if (jj >= j0 && jj < j1 && 32 * jj + 4 * c4 < kNumBeta) *reinterpret_cast<float4*>(dst + 32 * jj) = pre[jj];
+        };
+        // rows of the A image past the betas, k = 400..415: pose feature R_jaw - I (9), the template's 1, zero padding -- copied
+        // from the constants ring; lanes 0..31 of the wave: image 8 fw + (lane >> 2), float4 number lane & 3
+        auto write_tail = [&](int hb) {
+            if (lane < 32) {
+                const int r = 8 * fw + (lane >> 2), q = lane & 3;
+                const float* c = cst + (((hb >> 2) & 1) * kRound + (hb & 3) * HB + r) * CS;
+                float4 v = *reinterpret_cast<const float4*>(c + 4 * min(q, 2));  // D0..3 | D4..7 | D8 G0 G1 G2
+                if (q == 2) v = float4{v.x, 1.0f, 0.f, 0.f};
+                if (q == 3) v = float4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<float4*>(abuf + (hb & 1) * (HB * LD) + r * LD + kNumBeta + 4 * q) = v;
+            }
+        };
+        load_a(0);  // in flight before anything else happens in this workgroup
+        stamp(1);
+        phase_barrier();  // the arrival words are zero
+        write_a(0, 0, 4);
+        arrive(parts, lane);
+        write_a(0, 4, 8);
+        arrive(parts + 1, lane);
+        write_a(0, 8, 13);
+        arrive(parts + 2, lane);
+        stamp(2);
+        phase_barrier();  // B0: constants round 0 is in LDS
+        // (requested only now: the CU's load queue is full of basis at this point and a wave that cannot issue cannot arrive --
+        // with these 13 requests in front of B0 the mma waves stood at it for 2 k cycles)
+        if (H > 1) load_a(1);
+#pragma unroll 1
+        for (int h = 0; h < H; ++h) {
+            if (h < 4) stamp(16 + 4 * h);
+            if (h + 1 < H) {
+                // phase 0 is the one phase whose writes the mma waves end up waiting for (the rows arrive behind the basis stream):
+                // issue them ahead of the MFMAs; everywhere else a stager instruction may wait for a gap
+                if (h == 0) __builtin_amdgcn_s_setprio(2);
+                write_a(h + 1, 0, 13);
+                write_tail(h + 1);
+                if (h == 0) __builtin_amdgcn_s_setprio(DAD3D_PIPE_STAGER_PRIO);
+            }
+            if (h < 4) stamp(17 + 4 * h);
+            if (h + 2 < H) load_a(h + 2);
+            if (h < 4) stamp(18 + 4 * h);
+            phase_barrier();  // A(h)
+            if (h < 4) stamp(19 + 4 * h);
+        }
+        stamp(5);
+        if (trace && lane == 0) trace[13] = wall_clock64();
+        return;
+    }
+
+    // ================================================== mma waves ===========================================================
+    // wave w owns columns [16 w, 16 w + 16) of the tile for both 16-image row blocks of every half-block. MFMA step (G, s):
+    // lane (q = lane >> 4, n = lane & 15) contributes basis row k = 16 G + 4 q + s, so its A operand for s = 0..3 is the
+    // float4 at A[16 m + n][16 G + 4 q] of the row-major LDS image and its B operand the float4 packed for (G, w, lane).
+    const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
+    // -- constants of 128 images at a time (a "round"): lanes 0..31 of wave w take images 128 r + 32 w + lane ------------------
+    f4u raw0 = {}, raw1 = {}, raw2 = {};  // (kept in the loaded type: a copy would make the wave wait for the load on the spot)
+    float raw_scale = 0.f;
+    auto load_raw = [&](int r) {  // params[400..412] of the row, a phase before they are needed
+        const float* prow = a.params + (size_t)min(r * kRound + 32 * wave + (lane & 31), B - 1) * P + kNumBeta;
+        raw0 = *reinterpret_cast<const f4u*>(prow), raw1 = *reinterpret_cast<const f4u*>(prow + 4), raw2 = *reinterpret_cast<const f4u*>(prow + 8);
+        raw_scale = prow[12];
+    };
+    auto write_round = [&](int r, bool first) {
+        // [400,403) jaw | [403,409) 6-DoF rotation | [409,412) translation | [412] scale   (FlameParams.from_3dmm, flame.py:48-73)
+        const float jaw[3] = {raw0.x, raw0.y, raw0.z};
+        const float rot6[6] = {raw0.w, raw1.x, raw1.y, raw1.z, raw1.w, raw2.x};
+        float D[9], G[9];
+        rodrigues_minus_identity_lean(jaw, D);  // pose feature of the jaw (smplx lbs step 3) = R_jaw - I
+        rot6_to_matrix_lean(rot6, G);
+        const float s = fmaxf(raw_scale + 1.0f, 1e-8f);  // head_mesh.py:39
+        if (first && wave == 0 && lane < 32) {
+            // rows of A(0) past the betas, k = 400..415: pose feature R_jaw - I, the template's 1, zero padding (later half-blocks:
+            // the stagers copy them out of the ring)
+            float4* tail = reinterpret_cast<float4*>(abuf + lane * LD + kNumBeta);
+            tail[0] = float4{D[0], D[1], D[2], D[3]};
+            tail[1] = float4{D[4], D[5], D[6], D[7]};
+            tail[2] = float4{D[8], 1.0f, 0.f, 0.f};
+            tail[3] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (lane < 32) {
+            float4* c = reinterpret_cast<float4*>(cst + ((r & 1) * kRound + 32 * wave + lane) * CS);
+            c[0] = float4{D[0], D[1], D[2], D[3]};
+            c[1] = float4{D[4], D[5], D[6], D[7]};
+            c[2] = float4{D[8], G[0], G[1], G[2]};
+            c[3] = float4{G[3], G[4], G[5], G[6]};
+            c[4] = float4{G[7], G[8], s, raw2.y};
+            c[5] = float4{raw2.z, 0.f, 0.f, 0.f};
+            const int b = r * kRound + 32 * wave + lane;
+            if ((a.flags & DAD3D_MUTATE_PARAMS) && tile == 0 && b < B)
+                a.params[(size_t)b * P + kNumBeta + 11] = 0.0f;  // translation z := 0 (head_mesh.py:41)
+        }
+    };
+    load_raw(0);
+    float4 bq[KG];  // the wave's basis slice, resident for the launch
+#pragma unroll
+    for (int G = 0; G < 6; ++G) bq[G] = bsrc[(size_t)G * 256];
+    // -- epilogue role: the wave finishes images [8 w, 8 w + 8) of every half-block; lane = (image ei, vertex group eu) walks the
+    // vertices eu, eu + 8, eu + 16 of the tile. Their weights and landmark slots stay in registers for the launch.
+    const int ei = lane & 7, eu = lane >> 3, li = 8 * wave + ei;
+    float vW[3], vw2[3];
+    int lh[3], ln[3];
+    bool vl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int j = eu + 8 * k;
+        vl[k] = j < TV && v0 + j < a.n_verts;
+        const float4 t = vl[k] ? a.vtab[v0 + j] : float4{0.f, 0.f, __int_as_float(-1), __int_as_float(-1)};
+        vW[k] = t.x, vw2[k] = t.y, lh[k] = a.n_lmk > 0 ? __float_as_int(t.z) : -1, ln[k] = __float_as_int(t.w);
+    }
+    const float zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
+    const unsigned nl = (unsigned)a.n_lmk;
+    float4 c0, c1, c2, c3, c4v, c5;  // the constants of this lane's image for the half-block about to be finished
+    auto load_consts = [&](int hb) {
+        const float4* c = reinterpret_cast<const float4*>(cst + (((hb >> 2) & 1) * kRound + (hb & 3) * HB + li) * CS);
+        c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4v = c[4], c5 = c[5];
+    };
+    // Stores address (uniform 64-bit base) + (32-bit byte offset of the lane): the host sends launches whose outputs pass 2 GB
+    // to the two-role kernel. A lane's three vertices sit at constant distances (8 vertices apart).
+    char* const base3 = reinterpret_cast<char*>(a.verts3d);
+    char* const basep = reinterpret_cast<char*>(a.proj);
+    char* const baselx = reinterpret_cast<char*>(a.lmk_xy);
+    char* const baselp = reinterpret_cast<char*>(a.lmk_px);
+    constexpr unsigned kProjBytes = TO2D ? 8u : 12u;
+    auto put_landmark = [&](unsigned b_nl, int slot, float ox, float oy) {
+        const unsigned off = (b_nl + (unsigned)slot) * 8u;
+        if (baselx) *reinterpret_cast<f2u*>(baselx + off) = f2u{ox, oy};
+        if (baselp) *reinterpret_cast<i2u*>(baselp + off) = i2u{(int)ox, (int)oy};  // numpy .astype(int): toward zero
+    };
+    // The epilogue of one half-block in pieces (the constants c0..c5 of the lane's image were loaded before the barrier that
+    // closed the half-block): begin = J_jaw + output offsets; fetch(k) = v_posed of the lane's k-th vertex out of the accumulator
+    // tile; finish(k) = skinning, rotation, projection, stores. In the steady state the pieces ride in the next GEMM's hooks.
+    float jx = 0.f, jy = 0.f, jz = 0.f, ex = 0.f, ey = 0.f, ez = 0.f;
+    const float* ot_e = nullptr;
+    unsigned e_vrow = 0, e_bnl = 0;  // (b V + v0 + eu), b n_lmk
+    bool live3[3] = {false, false, false}, livep[3] = {false, false, false}, livel[3] = {false, false, false};
+    auto epi_begin = [&](int hb) {
+        ot_e = otile + (hb & 1) * (HB * OS) + li * OS;
+        jx = ot_e[kJawCol], jy = ot_e[kJawCol + 1], jz = ot_e[kJawCol + 2];  // J_jaw of this image, from the GEMM
+        const int b = hb * HB + li;
+        e_vrow = (unsigned)b * (unsigned)a.n_verts + (unsigned)(v0 + eu);
+        e_bnl = (unsigned)b * nl;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool live = b < B && vl[k];
+            live3[k] = live && base3 != nullptr, livep[k] = live && basep != nullptr, livel[k] = live && lh[k] >= 0;
+        }
+    };
+    auto epi_fetch = [&](int k) {
+        const int j = eu + 8 * k;
+        ex = ot_e[3 * j], ey = ot_e[3 * j + 1], ez = ot_e[3 * j + 2];  // v_posed (template + blend shapes + pose correctives)
+    };
+    auto epi_finish = [&](int k) {
+        const float sc = c4v.z;
+        // smplx lbs steps 5-6 with only the jaw rotating: T.[v;1] = W v + w_jaw (R_jaw - I)(v - J_jaw)
+        const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
+        const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
+        const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
+        const float W = vW[k], w2 = vw2[k];
+        const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
+        const float px = pxy.x, py = pxy.y;
+        const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
+        // flame.py:226-228: R.v with R = [b1 b2 b3]
+        const f32x2 rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
+        const float rz = __builtin_fmaf(c4v.y, pz, __builtin_fmaf(c4v.x, py, c3.w * px));
+        // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+        const f32x2 oxy = (fma2(rxy, sc, f32x2{c4v.w, c5.x}) + 1.0f) / 2.0f * a.image_size;
+        const float ox = oxy.x, oy = oxy.y;
+        // eight lanes = eight consecutive vertices of one image: 96 / 64 contiguous bytes per store instruction
+        if (DAD3D_PIPE_ABLATE & 1) {
+            if (ox == 12345.678f) *reinterpret_cast<f3u*>(base3) = f3u{rxy.x, rxy.y, rz};
+        } else if (live3[k]) {
+            if (DAD3D_PIPE_NT) __builtin_nontemporal_store(f3u{rxy.x, rxy.y, rz}, reinterpret_cast<f3u*>(base3 + (e_vrow * 12u + 96u * k)));
+            else *reinterpret_cast<f3u*>(base3 + (e_vrow * 12u + 96u * k)) = f3u{rxy.x, rxy.y, rz};
+        }
+        if (!(DAD3D_PIPE_ABLATE & 1) && livep[k]) {
+            if (TO2D && DAD3D_PIPE_NT) __builtin_nontemporal_store(f2u{ox, oy}, reinterpret_cast<f2u*>(basep + (e_vrow * kProjBytes + 64u * k)));
+            else if (TO2D) *reinterpret_cast<f2u*>(basep + (e_vrow * kProjBytes + 64u * k)) = f2u{ox, oy};
+            else {
+                const f3u o3 = f3u{ox, oy, zsign * ((__builtin_fmaf(rz, sc, 0.0f) + 1.0f) / 2.0f * a.image_size)};
+                if (DAD3D_PIPE_NT) __builtin_nontemporal_store(o3, reinterpret_cast<f3u*>(basep + (e_vrow * kProjBytes + 96u * k)));
+                else *reinterpret_cast<f3u*>(basep + (e_vrow * kProjBytes + 96u * k)) = o3;
+            }
+        }
+        if (livel[k]) {
+            put_landmark(e_bnl, lh[k], ox, oy);
+            if (ln[k] >= 0) {  // duplicate indices in the landmark list: the chain goes on (rare; its loads wait, the rest does not)
+                put_landmark(e_bnl, ln[k], ox, oy);
+                for (int slot = a.lmk_next[ln[k]]; slot >= 0; slot = a.lmk_next[slot]) put_landmark(e_bnl, slot, ox, oy);
+            }
+        }
+    };
+    // hook of the steady-state GEMM: pieces of the previous half-block's epilogue, a fetch two groups before its finish
+    int hook_hb = 0;
+    auto epi_hook = [&](int G) {
+        if (DAD3D_PIPE_ABLATE & 2) return;
+        if (G == 0) epi_begin(hook_hb), epi_fetch(0);
+        if (G == 3) epi_finish(0), epi_fetch(1);
+        if (G == 11) epi_finish(1), epi_fetch(2);
+        if (G == 19) epi_finish(2);
+    };
+    auto no_hook = [](int) {};
+    const float* afrag0 = abuf + (lane & 15) * LD + 4 * (lane >> 4);
+    float* const ot0 = otile + ((lane >> 4) * 4) * OS + wave * 16 + (lane & 15);
+    // accumulators -> LDS tile [image][column]; D layout: row = (lane >> 4) * 4 + reg, column = lane & 15
+    auto park = [&](int h, const f32x4 (&acc)[2]) {
+        float* ot = ot0 + (h & 1) * (HB * OS);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ot[(m * 16 + q) * OS] = acc[m][q];
+    };
+    const int n_rounds = (B + kRound - 1) / kRound;
+
+    phase_barrier();  // the arrival words are zero
+    // The rest of the basis slice, ALL of it in flight now: the stagers requested the first A image before they arrived at the
+    // barrier above, and a CU's vector loads return in order -- so the A image is not behind these 80 KB (requested up front,
+    // before the barrier, they put the first MFMA at 6.3 k cycles instead of 4.5 k), while the basis stream no longer waits for
+    // the GEMM to ask for it six groups at a time (first half-block 12.2 k cycles at that pace).
+#pragma unroll
+    for (int G = 6; G < KG; ++G) bq[G] = bsrc[(size_t)G * 256];
+    {   // the first half-block: A arrives in parts, the basis slice is still streaming into the registers. The constants of the
+        // first 128 images are computed between two of its groups: their ~250 instructions fill time the GEMM would spend waiting
+        // for the basis anyway, and nothing in front of the first MFMA waits for the params' tails.
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float4 af[2];
+        stamp(16);
+        gemm_groups<true, 0, 7>(afrag0, bq, acc, af, parts, no_hook);
+        stamp(1);
+        write_round(0, true);
+        if (wave == 0) arrive(parts + 2, lane);
+        stamp(4);
+        phase_barrier();  // B0
+        gemm_groups<true, 7, KG>(afrag0, bq, acc, af, parts, no_hook);
+        stamp(2);
+        park(0, acc);
+        stamp(17);
+    }
+    load_consts(0);
+    phase_barrier();  // A(0)
+    stamp(18);
+#pragma unroll 1
+    for (int h = 1; h < H; ++h) {
+        // round r covers half-blocks 4 r .. 4 r + 3: written in phase 4 r - 2 (the stagers read it from phase 4 r - 1 on), its
+        // params requested a phase before that. The ring slot's previous tenant (round r - 2) was consumed by phase 4 r - 5.
+        const int r = (h + 2) >> 2;
+        if (!(DAD3D_PIPE_ABLATE & 4) && (h & 3) == 2 && r < n_rounds) write_round(r, false);
+        if ((h & 3) == 1 && ((h + 3) >> 2) < n_rounds) load_raw((h + 3) >> 2);
+        if (h < 4) stamp(16 + 4 * h);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float4 af[2];
+        hook_hb = h - 1;  // half-block h - 1 is finished inside the GEMM of half-block h
+        gemm_groups<false, 0, KG>(afrag0 + (h & 1) * (HB * LD), bq, acc, af, parts, epi_hook);
+        park(h, acc);
+        if (h < 4) stamp(17 + 4 * h);
+        load_consts(h);
+        phase_barrier();  // A(h)
+        if (h < 4) stamp(18 + 4 * h);
+    }
+    // the last half-block has no GEMM to ride in
+    stamp(3);
+    epi_begin(H - 1);
+    epi_fetch(0);
+    epi_finish(0);
+    epi_fetch(1);
+    epi_finish(1);
+    epi_fetch(2);
+    epi_finish(2);
+    stamp(5);
+    if (trace && lane == 0) trace[13] = wall_clock64();
+}
+
+size_t flame_decode_pipe_lds_bytes() { return (size_t)Lds::total * sizeof(float); }
+
+dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s) {
+    static PerDeviceOnce attr_done;
+    const int dev = PerDeviceOnce::current();
+    const size_t lds = flame_decode_pipe_lds_bytes();
+    if (!attr_done.done(dev)) {
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_pipe_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_pipe_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done.set(dev);
+    }
+    if (a.flags & DAD3D_TO_2D) hipLaunchKernelGGL(flame_decode_pipe_kernel<true>, dim3(a.n_tiles), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(flame_decode_pipe_kernel<false>, dim3(a.n_tiles), dim3(512), lds, s, a);
+    DAD3D_HIP_TRY(hipGetLastError());
+    return DAD3D_OK;
+}
+
+}  // namespace dad3d
