@@ -453,14 +453,13 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         dad3d_status st = grad_inputs_prepare(h, batch, s);
         if (st) return st;
     }
-    // The pipelined single-role kernel (flame_decode_pipe.hip): inference outputs of a covered model. It walks the batch in
-    // half-blocks of 32 images; a launch of 33..64 images is the one shape where the two-role kernel's single 64-image pass -- as
-    // long as the basis takes to stream in -- is still ahead (12.8 against 14.3 us at 64; 8.2 / 9.3 / 18.2 / 38.5 / 137 / 268 us
-    // against 8.3 / 11.5 / 22.4 / 42.5 / 158 / 325 at 1 / 32 / 96 / 256 / 1024 / 2048: profiles/r04_ab_decode.txt).
+    // The pipelined single-role kernel (flame_decode_pipe.hip) takes every inference launch of a covered model (jaw-only, the
+    // dad_3dnet.yaml params layout, no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3, outputs below 2 GB); the two-role kernel of
+    // rounds 1-3 keeps the rest and the training forward. profiles/r04_ab_decode.txt has both at every batch size.
     const int choice = decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
-    if (pipe_covers && choice != 1 && (batch <= kPipeHalf || batch > 2 * kPipeHalf || choice == 2)) {
+    if (pipe_covers && choice != 1) {
         PipeArgs pa{};
         pa.params = params;
         pa.bpack = h->c->d_bpack_pipe;

@@ -879,7 +879,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_kernel(DecodeArgs a) {
 #define DAD3D_NT_STORES 0  // lines for the end-of-kernel write-back); measured in round 4, see profiles/r04_kernel_log.md
 #endif
     auto st = [](float* p, float v) {
-        if (DAD3D_NT_STORES) __builtin_nontemporal_store(v, p);
+        if (DAD3D_NT_STORES == 2) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");  // write-through
+        else if (DAD3D_NT_STORES) __builtin_nontemporal_store(v, p);
         else *p = v;
     };
     auto put_landmark = [&](unsigned li, int slot, float ox, float oy) {

@@ -40,9 +40,9 @@
 #ifndef DAD3D_PIPE_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no vertex stores, 2 = no epilogue in the GEMM,
 #define DAD3D_PIPE_ABLATE 0  // 4 = no constants rounds after the first. Results wrong, timing meaningful. 0 in the product
 #endif
-#ifndef DAD3D_PIPE_NT  // 1 = non-temporal vertex stores: the outputs (105 KB per image) stream through the L2 instead of evicting the
-#define DAD3D_PIPE_NT 1  // basis and piling up dirty lines for the end-of-kernel write-back: 21.95 / 38.2 against 23.5 / 40.7 us at B = 128 / 256
-#endif
+#ifndef DAD3D_PIPE_STORE_AUX  // cache policy of the vertex stores (buffer-op aux bits: 1 = sc0, 2 = nt, 16 = sc1). 2 = non-temporal: the
+#define DAD3D_PIPE_STORE_AUX 16 // outputs (105 KB per image) stream through the L2 instead of evicting the basis and piling up dirty lines
+#endif                          // for the end-of-kernel write-back: 21.95 / 38.2 against 23.5 / 40.7 us at B = 128 / 256 (plain stores)
 #ifndef DAD3D_PIPE_STAGER_PRIO  // s_setprio of the stager waves (the mma waves stay at 0). Their instructions are few and every
 #define DAD3D_PIPE_STAGER_PRIO 0  // one of them sits on a latency chain -- but priority 1 measured slower at every size (14.9 / 23.7 / 40.5 / 139.2
                                   // against 14.0 / 22.6 / 39.5 / 138.4 us at B = 64 / 128 / 256 / 1024, same call; 3: as 1)
@@ -58,6 +58,8 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B acce
 typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));  // 12 B store
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8 B store to a 4-byte aligned address
 typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
 
 constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
@@ -76,7 +78,8 @@ struct Lds {
     static constexpr int o_off = a_off + 2 * HB * LD;        // [2][HB][OS]      accumulators, double buffered
     static constexpr int c_off = o_off + 2 * HB * OS;        // [2][kRound][CS]  per-image constants, two rounds
     static constexpr int y_off = c_off + 2 * kRound * CS;    // [4] arrival words of the first A image's three parts
-    static constexpr int total = y_off + 4;
+    static constexpr int v_off = y_off + 4;                  // [TV] float4: the tile's rows of the vertex table (last half-block)
+    static constexpr int total = v_off + 4 * TV;
     static_assert(total * 4 <= 160 * 1024, "LDS budget of one CU");
 };
 
@@ -97,43 +100,101 @@ __device__ __forceinline__ void phase_barrier() {
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, f32x2{b, b}, c); }
 
+// ---- one (vertex, image): skinning, +MESH_OFFSET_Z, 6-DoF rotation, projection, stores ---------------------------------------------
+struct EpiCtx {  // uniform over the workgroup
+    char *lx, *lp;                    // landmark outputs (float / int pixels) or null
+    const int* lmk_next;
+    float image_size, zsign;
+};
+// One lane's vertex of one image. c0..c5 = the image's constants (D 9 | G 9 | s tx ty), (jx, jy, jz) = its jaw joint, (ex, ey, ez) =
+// v_posed of the vertex; W, w2 = sum of the five skinning weights, the jaw's; lh, ln = first landmark slot of the vertex, the slot
+// chained after it; st3 / stp / stl = store the 3-D vertex / the projection / landmarks (image inside the batch, vertex inside the
+// mesh, output given); vrow = b * V + (a vertex of the tile): the stores go to vertex vrow + VOFF; bnl = b * n_lmk.
+template <bool TO2D, int VOFF>
+__device__ __forceinline__ void finish_vertex(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, float4 c0, float4 c1, float4 c2, float4 c3, float4 c4, float4 c5, float jx, float jy, float jz, float ex, float ey, float ez,
+                                              float W, float w2, int lh, int ln, bool st3, bool stp, bool stl, unsigned vrow, unsigned bnl) {
+    const float sc = c4.z;
+    // smplx lbs steps 5-6 with only the jaw rotating: T.[v;1] = W v + w_jaw (R_jaw - I)(v - J_jaw)
+    const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
+    const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
+    const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
+    const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
+    const float px = pxy.x, py = pxy.y;
+    const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
+    // flame.py:226-228: R.v with R = [b1 b2 b3]
+    const f32x2 rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
+    const float rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
+    // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+    const f32x2 oxy = (fma2(rxy, sc, f32x2{c4.w, c5.x}) + 1.0f) / 2.0f * cx.image_size;
+    const float ox = oxy.x, oy = oxy.y;
+    // neighbouring lanes = consecutive vertices of one image: contiguous runs per store instruction
+    if (DAD3D_PIPE_ABLATE & 1) {
+        if (ox == 12345.678f) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{rxy.x, rxy.y, rz}), rs3, 0, 0, 0);
+    } else {
+        if (st3)
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{rxy.x, rxy.y, rz}), rs3, (int)(vrow * 12u), 12 * VOFF,
+                                                  DAD3D_PIPE_STORE_AUX);
+        if (stp) {
+            if (TO2D) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{ox, oy}), rsp, (int)(vrow * 8u), 8 * VOFF, DAD3D_PIPE_STORE_AUX);
+            } else {
+                const f3u o3 = f3u{ox, oy, cx.zsign * ((__builtin_fmaf(rz, sc, 0.0f) + 1.0f) / 2.0f * cx.image_size)};
+                __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, o3), rsp, (int)(vrow * 12u), 12 * VOFF, DAD3D_PIPE_STORE_AUX);
+            }
+        }
+    }
+    if (stl) {
+        auto put = [&](int slot) {
+            const unsigned off = (bnl + (unsigned)slot) * 8u;
+            if (cx.lx) *reinterpret_cast<f2u*>(cx.lx + off) = f2u{ox, oy};
+            if (cx.lp) *reinterpret_cast<i2u*>(cx.lp + off) = i2u{(int)ox, (int)oy};  // numpy .astype(int): toward zero
+        };
+        put(lh);
+        if (ln >= 0) {  // duplicate indices in the landmark list: the chain goes on (rare; its loads wait, the rest does not)
+            put(ln);
+            for (int slot = cx.lmk_next[ln]; slot >= 0; slot = cx.lmk_next[slot]) put(slot);
+        }
+    }
+}
+
 // ---- the GEMM of one half-block on one mma wave: acc[m] += A[16 m .. 16 m + 16][k] * basis[k][16 columns] --------------------
-// Groups [G0, G1) of 16 k; `af` carries the prefetched A fragments from one call to the next. FIRST: the launch's first
+// Groups [G0, G1) of 16 k, RB row blocks of 16 images (2 = a half-block); `af` carries the prefetched A fragments from one call to
+// the next. FIRST: the launch's first
 // half-block -- the A image arrives in three parts (arrival words) and the basis slice is still on its way into the registers: the
 // first half-block of a launch runs at the pace of the basis stream (25.6 MB through every CU's share of the memory system),
 // not at the pace of the matrix pipe.
 // hook(G) runs between the MFMAs of group G and those of group G + 1: the previous half-block's epilogue rides here in pieces,
 // so that its LDS round trips hide and its stores leave spread over the GEMM instead of as one burst of every CU.
-template <bool FIRST, int G0, int G1, class Hook>
-__device__ __forceinline__ void gemm_groups(const float* afrag, const float4 (&bq)[KG], f32x4 (&acc)[2], float4 (&af)[2], lds_int* parts,
+template <bool FIRST, int G0, int G1, int RB, class Hook>
+__device__ __forceinline__ void gemm_groups(const float* afrag, const float4 (&bq)[KG], f32x4 (&acc)[RB], float4 (&af)[RB], lds_int* parts,
                                             Hook&& hook) {
-    float4 an[2] = {};
+    float4 an[RB] = {};
     if (G0 == 0) {
         if (FIRST) wait_ge(parts, 4);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
+        for (int m = 0; m < RB; ++m) af[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD);
     }
 #pragma unroll
     for (int G = G0; G < G1; ++G) {
         if (FIRST && G + 1 == 8) wait_ge(parts + 1, 4);
-        if (FIRST && G + 1 == 16) wait_ge(parts + 2, 5);  // four stagers and the mma wave that wrote the tail rows
+        if (FIRST && G + 1 == 16) wait_ge(parts + 2, 4 + RB / 2);  // four stagers and the mma waves that wrote the tail rows
         if (G + 1 < KG) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
+            for (int m = 0; m < RB; ++m) an[m] = *reinterpret_cast<const float4*>(afrag + m * 16 * LD + 16 * (G + 1));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const float bv = s == 0 ? bq[G].x : s == 1 ? bq[G].y : s == 2 ? bq[G].z : bq[G].w;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < RB; ++m) {
                 const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) af[m] = an[m];
+        for (int m = 0; m < RB; ++m) af[m] = an[m];
         hook(G);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -148,6 +209,9 @@ __device__ __forceinline__ void gemm_groups(const float* afrag, const float4 (&b
 // h - 1 (accumulator tile (h - 1) & 1, constants already in registers) in the gaps -- park it in tile h & 1 and load its constants
 // into registers; stagers write image (h + 1) & 1 -- last read by GEMM(h - 1) -- and request the rows of half-block h + 2.
 // TO2D: `proj` is [B,V,2] (head_mesh.py:44-45 `to_2d`), else [B,V,3]. DAD3D_ZERO_ROTATION launches take the two-role kernel.
+// (Measured and dropped, profiles/r04_kernel_log.md: a launch of 33..64 images as ONE pass of four row blocks over both A images,
+// all eight waves finishing both half-blocks -- 13.2 us at B = 64 against 12.8 for the two-phase pipeline: every store of the
+// launch then leaves at the very end.)
 template <bool TO2D>
 __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -166,6 +230,40 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     if (trace && lane == 0) trace[12] = wall_clock64();
     stamp(0);
     if (tid < 4) __hip_atomic_store(parts + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned nl = (unsigned)a.n_lmk;
+    EpiCtx cx;
+    // 3d_vertices / projection leave as raw buffer stores: (uniform resource) + (32-bit byte offset of the lane) + immediate
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.verts3d), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.proj), 0, 0x7fffffff, 0x00020000);
+    cx.lx = reinterpret_cast<char*>(a.lmk_xy), cx.lp = reinterpret_cast<char*>(a.lmk_px);
+    cx.lmk_next = a.lmk_next;
+    cx.image_size = a.image_size;
+    cx.zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
+    float4* const vt_lds = reinterpret_cast<float4*>(smem + Lds::v_off);
+    // The LAST half-block has no GEMM to ride in and nothing left to stage: all eight waves finish it, four images each, lane =
+    // (image fi of the wave's four, vertex fu of sixteen) -> vertices fu and, for fu < 4, fu + 16; sixteen lanes = sixteen
+    // consecutive vertices of one image. The vertex table comes from LDS (parked there at the start by a stager wave).
+    auto final_epilogue = [&](int hb) {
+        const int fi = lane & 3, fu = lane >> 2, fli = 4 * wave + fi, b = hb * HB + fli;
+        const float4* cp = reinterpret_cast<const float4*>(cst + (((hb >> 2) & 1) * kRound + (hb & 3) * HB + fli) * CS);
+        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3], c4 = cp[4], c5 = cp[5];
+        const float* ot = otile + (hb & 1) * (HB * OS) + fli * OS;
+        const float jx = ot[kJawCol], jy = ot[kJawCol + 1], jz = ot[kJawCol + 2];
+        const unsigned vrow = (unsigned)b * (unsigned)a.n_verts + (unsigned)(v0 + fu), bnl = (unsigned)b * nl;
+        {
+            const float4 t = vt_lds[fu];
+            const bool live = b < B && v0 + fu < a.n_verts;
+            finish_vertex<TO2D, 0>(cx, rs3, rsp, c0, c1, c2, c3, c4, c5, jx, jy, jz, ot[3 * fu], ot[3 * fu + 1], ot[3 * fu + 2], t.x, t.y, __float_as_int(t.z), __float_as_int(t.w),
+                                   live && a.verts3d != nullptr, live && a.proj != nullptr, live && nl > 0 && __float_as_int(t.z) >= 0, vrow, bnl);
+        }
+        if (fu < TV - 16) {
+            const int j = fu + 16;
+            const float4 t = vt_lds[j];
+            const bool live = b < B && v0 + j < a.n_verts;
+            finish_vertex<TO2D, 16>(cx, rs3, rsp, c0, c1, c2, c3, c4, c5, jx, jy, jz, ot[3 * j], ot[3 * j + 1], ot[3 * j + 2], t.x, t.y, __float_as_int(t.z), __float_as_int(t.w),
+                                    live && a.verts3d != nullptr, live && a.proj != nullptr, live && nl > 0 && __float_as_int(t.z) >= 0, vrow, bnl);
+        }
+    };
 
     if (wave >= 4) {
         // =============================================== stager waves =====================================================
@@ -174,22 +272,24 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         // thread copies the float4s (row srow, 32 j + 4 c4), j = 0..12, of the half-block's 32 params rows (params[:, 0:400] are
         // the betas: shape 300 + expression 100, flame.py:192-200 with nothing to pad). Rows are 4-byte aligned (413 floats).
         const int srow = ht >> 3, c4 = ht & 7;
-        float4 pre[13];  // the thread's share of the NEXT A image, requested a phase ahead
-        auto load_a = [&](int hb) {
+        float4 pre[13];   // the thread's share of the NEXT A image, requested a phase ahead
+        auto load_rows = [&](int hb, float4 (&dst)[13]) {
             const float* prow = a.params + (size_t)min(hb * HB + srow, B - 1) * P;  // rows past the batch re-read its last row
 #pragma unroll
             for (int jj = 0; jj < 13; ++jj) {
                 const int kk = (32 * jj + 28 < kNumBeta) ? 32 * jj + 4 * c4 : min(32 * jj + 4 * c4, kNumBeta - 4);
                 const f4u v = *reinterpret_cast<const f4u*>(prow + kk);
-                pre[jj] = float4{v.x, v.y, v.z, v.w};
+                dst[jj] = float4{v.x, v.y, v.z, v.w};
             }
         };
-        auto write_a = [&](int hb, int j0, int j1) {  // slabs [j0, j1) of 32 k; MFMA groups [0,8) [8,16) [16,26) = slabs [0,4) [4,8) [8,13)
+        auto write_rows = [&](int hb, int j0, int j1, const float4 (&src)[13]) {  // slabs [j0, j1) of 32 k; MFMA groups [0,8) [8,16) [16,26) = slabs [0,4) [4,8) [8,13)
             float* dst = abuf + (hb & 1) * (HB * LD) + srow * LD + 4 * c4;
 #pragma unroll
             for (int jj = 0; jj < 13; ++jj)
-                if (jj >= j0 && jj < j1 && 32 * jj + 4 * c4 < kNumBeta) *reinterpret_cast<float4*>(dst + 32 * jj) = pre[jj];
+                if (jj >= j0 && jj < j1 && 32 * jj + 4 * c4 < kNumBeta) *reinterpret_cast<float4*>(dst + 32 * jj) = src[jj];
         };
+        auto load_a = [&](int hb) { load_rows(hb, pre); };
+        auto write_a = [&](int hb, int j0, int j1) { write_rows(hb, j0, j1, pre); };
         // rows of the A image past the betas, k = 400..415: pose feature R_jaw - I (9), the template's 1, zero padding -- copied
         // from the constants ring; lanes 0..31 of the wave: image 8 fw + (lane >> 2), float4 number lane & 3
         auto write_tail = [&](int hb) {
@@ -203,6 +303,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
             }
         };
         load_a(0);  // in flight before anything else happens in this workgroup
+        if (fw == 3 && lane < TV)  // the tile's rows of the vertex table, for the last half-block (read behind the last barrier)
+            vt_lds[lane] = v0 + lane < a.n_verts ? a.vtab[v0 + lane] : float4{0.f, 0.f, __int_as_float(-1), __int_as_float(-1)};
         stamp(1);
         phase_barrier();  // the arrival words are zero
         write_a(0, 0, 4);
@@ -213,8 +315,9 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         arrive(parts + 2, lane);
         stamp(2);
         phase_barrier();  // B0: constants round 0 is in LDS
-        // (requested only now: the CU's load queue is full of basis at this point and a wave that cannot issue cannot arrive --
-        // with these 13 requests in front of B0 the mma waves stood at it for 2 k cycles)
+        // (requested only now: a request issued while the CU's load queue is full of basis blocks its wave -- with these 13 in front
+        // of B0 the mma waves stood at that barrier for 2 k cycles -- and requested together with the first image, in front of the
+        // basis, they put the first MFMA 1.2 k cycles later: 13.1 against 12.8 us at B = 64)
         if (H > 1) load_a(1);
 #pragma unroll 1
         for (int h = 0; h < H; ++h) {
@@ -233,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
             phase_barrier();  // A(h)
             if (h < 4) stamp(19 + 4 * h);
         }
+        final_epilogue(H - 1);
         stamp(5);
         if (trace && lane == 0) trace[13] = wall_clock64();
         return;
@@ -260,8 +364,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         rot6_to_matrix_lean(rot6, G);
         const float s = fmaxf(raw_scale + 1.0f, 1e-8f);  // head_mesh.py:39
         if (first && wave == 0 && lane < 32) {
-            // rows of A(0) past the betas, k = 400..415: pose feature R_jaw - I, the template's 1, zero padding (later half-blocks:
-            // the stagers copy them out of the ring)
+            // rows of the first A image past the betas, k = 400..415: pose feature R_jaw - I, the template's 1, zero padding
+            // (later half-blocks: the stagers copy them out of the ring)
             float4* tail = reinterpret_cast<float4*>(abuf + lane * LD + kNumBeta);
             tail[0] = float4{D[0], D[1], D[2], D[3]};
             tail[1] = float4{D[4], D[5], D[6], D[7]};
@@ -298,31 +402,17 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         const float4 t = vl[k] ? a.vtab[v0 + j] : float4{0.f, 0.f, __int_as_float(-1), __int_as_float(-1)};
         vW[k] = t.x, vw2[k] = t.y, lh[k] = a.n_lmk > 0 ? __float_as_int(t.z) : -1, ln[k] = __float_as_int(t.w);
     }
-    const float zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
-    const unsigned nl = (unsigned)a.n_lmk;
-    float4 c0, c1, c2, c3, c4v, c5;  // the constants of this lane's image for the half-block about to be finished
+    float4 k0, k1, k2, k3, k4, k5;  // the constants of this lane's image for the half-block about to be finished
     auto load_consts = [&](int hb) {
         const float4* c = reinterpret_cast<const float4*>(cst + (((hb >> 2) & 1) * kRound + (hb & 3) * HB + li) * CS);
-        c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4v = c[4], c5 = c[5];
+        k0 = c[0], k1 = c[1], k2 = c[2], k3 = c[3], k4 = c[4], k5 = c[5];
     };
-    // Stores address (uniform 64-bit base) + (32-bit byte offset of the lane): the host sends launches whose outputs pass 2 GB
-    // to the two-role kernel. A lane's three vertices sit at constant distances (8 vertices apart).
-    char* const base3 = reinterpret_cast<char*>(a.verts3d);
-    char* const basep = reinterpret_cast<char*>(a.proj);
-    char* const baselx = reinterpret_cast<char*>(a.lmk_xy);
-    char* const baselp = reinterpret_cast<char*>(a.lmk_px);
-    constexpr unsigned kProjBytes = TO2D ? 8u : 12u;
-    auto put_landmark = [&](unsigned b_nl, int slot, float ox, float oy) {
-        const unsigned off = (b_nl + (unsigned)slot) * 8u;
-        if (baselx) *reinterpret_cast<f2u*>(baselx + off) = f2u{ox, oy};
-        if (baselp) *reinterpret_cast<i2u*>(baselp + off) = i2u{(int)ox, (int)oy};  // numpy .astype(int): toward zero
-    };
-    // The epilogue of one half-block in pieces (the constants c0..c5 of the lane's image were loaded before the barrier that
-    // closed the half-block): begin = J_jaw + output offsets; fetch(k) = v_posed of the lane's k-th vertex out of the accumulator
-    // tile; finish(k) = skinning, rotation, projection, stores. In the steady state the pieces ride in the next GEMM's hooks.
+    // The epilogue of one half-block in pieces (the constants of the lane's image were loaded before the barrier that closed the
+    // half-block): begin = J_jaw + output offsets; fetch(k) = v_posed of the lane's k-th vertex out of the accumulator tile;
+    // finish(k) = skinning, rotation, projection, stores. The pieces ride in the next GEMM's hooks.
     float jx = 0.f, jy = 0.f, jz = 0.f, ex = 0.f, ey = 0.f, ez = 0.f;
     const float* ot_e = nullptr;
-    unsigned e_vrow = 0, e_bnl = 0;  // (b V + v0 + eu), b n_lmk
+    unsigned e_vrow = 0, e_bnl = 0;  // b V + v0 + eu, b n_lmk
     bool live3[3] = {false, false, false}, livep[3] = {false, false, false}, livel[3] = {false, false, false};
     auto epi_begin = [&](int hb) {
         ot_e = otile + (hb & 1) * (HB * OS) + li * OS;
@@ -333,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const bool live = b < B && vl[k];
-            live3[k] = live && base3 != nullptr, livep[k] = live && basep != nullptr, livel[k] = live && lh[k] >= 0;
+            live3[k] = live && a.verts3d != nullptr, livep[k] = live && a.proj != nullptr, livel[k] = live && lh[k] >= 0;
         }
     };
     auto epi_fetch = [&](int k) {
@@ -341,44 +431,9 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         ex = ot_e[3 * j], ey = ot_e[3 * j + 1], ez = ot_e[3 * j + 2];  // v_posed (template + blend shapes + pose correctives)
     };
     auto epi_finish = [&](int k) {
-        const float sc = c4v.z;
-        // smplx lbs steps 5-6 with only the jaw rotating: T.[v;1] = W v + w_jaw (R_jaw - I)(v - J_jaw)
-        const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
-        const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
-        const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
-        const float W = vW[k], w2 = vw2[k];
-        const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
-        const float px = pxy.x, py = pxy.y;
-        const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
-        // flame.py:226-228: R.v with R = [b1 b2 b3]
-        const f32x2 rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
-        const float rz = __builtin_fmaf(c4v.y, pz, __builtin_fmaf(c4v.x, py, c3.w * px));
-        // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
-        const f32x2 oxy = (fma2(rxy, sc, f32x2{c4v.w, c5.x}) + 1.0f) / 2.0f * a.image_size;
-        const float ox = oxy.x, oy = oxy.y;
-        // eight lanes = eight consecutive vertices of one image: 96 / 64 contiguous bytes per store instruction
-        if (DAD3D_PIPE_ABLATE & 1) {
-            if (ox == 12345.678f) *reinterpret_cast<f3u*>(base3) = f3u{rxy.x, rxy.y, rz};
-        } else if (live3[k]) {
-            if (DAD3D_PIPE_NT) __builtin_nontemporal_store(f3u{rxy.x, rxy.y, rz}, reinterpret_cast<f3u*>(base3 + (e_vrow * 12u + 96u * k)));
-            else *reinterpret_cast<f3u*>(base3 + (e_vrow * 12u + 96u * k)) = f3u{rxy.x, rxy.y, rz};
-        }
-        if (!(DAD3D_PIPE_ABLATE & 1) && livep[k]) {
-            if (TO2D && DAD3D_PIPE_NT) __builtin_nontemporal_store(f2u{ox, oy}, reinterpret_cast<f2u*>(basep + (e_vrow * kProjBytes + 64u * k)));
-            else if (TO2D) *reinterpret_cast<f2u*>(basep + (e_vrow * kProjBytes + 64u * k)) = f2u{ox, oy};
-            else {
-                const f3u o3 = f3u{ox, oy, zsign * ((__builtin_fmaf(rz, sc, 0.0f) + 1.0f) / 2.0f * a.image_size)};
-                if (DAD3D_PIPE_NT) __builtin_nontemporal_store(o3, reinterpret_cast<f3u*>(basep + (e_vrow * kProjBytes + 96u * k)));
-                else *reinterpret_cast<f3u*>(basep + (e_vrow * kProjBytes + 96u * k)) = o3;
-            }
-        }
-        if (livel[k]) {
-            put_landmark(e_bnl, lh[k], ox, oy);
-            if (ln[k] >= 0) {  // duplicate indices in the landmark list: the chain goes on (rare; its loads wait, the rest does not)
-                put_landmark(e_bnl, ln[k], ox, oy);
-                for (int slot = a.lmk_next[ln[k]]; slot >= 0; slot = a.lmk_next[slot]) put_landmark(e_bnl, slot, ox, oy);
-            }
-        }
+        if (k == 0) finish_vertex<TO2D, 0>(cx, rs3, rsp, k0, k1, k2, k3, k4, k5, jx, jy, jz, ex, ey, ez, vW[0], vw2[0], lh[0], ln[0], live3[0], livep[0], livel[0], e_vrow, e_bnl);
+        if (k == 1) finish_vertex<TO2D, 8>(cx, rs3, rsp, k0, k1, k2, k3, k4, k5, jx, jy, jz, ex, ey, ez, vW[1], vw2[1], lh[1], ln[1], live3[1], livep[1], livel[1], e_vrow, e_bnl);
+        if (k == 2) finish_vertex<TO2D, 16>(cx, rs3, rsp, k0, k1, k2, k3, k4, k5, jx, jy, jz, ex, ey, ez, vW[2], vw2[2], lh[2], ln[2], live3[2], livep[2], livel[2], e_vrow, e_bnl);
     };
     // hook of the steady-state GEMM: pieces of the previous half-block's epilogue, a fetch two groups before its finish
     int hook_hb = 0;
@@ -415,18 +470,18 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float4 af[2];
         stamp(16);
-        gemm_groups<true, 0, 7>(afrag0, bq, acc, af, parts, no_hook);
+        gemm_groups<true, 0, 7, 2>(afrag0, bq, acc, af, parts, no_hook);
         stamp(1);
         write_round(0, true);
         if (wave == 0) arrive(parts + 2, lane);
         stamp(4);
         phase_barrier();  // B0
-        gemm_groups<true, 7, KG>(afrag0, bq, acc, af, parts, no_hook);
+        gemm_groups<true, 7, KG, 2>(afrag0, bq, acc, af, parts, no_hook);
         stamp(2);
         park(0, acc);
         stamp(17);
     }
-    load_consts(0);
+    if (H > 1) load_consts(0);
     phase_barrier();  // A(0)
     stamp(18);
 #pragma unroll 1
@@ -440,22 +495,15 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float4 af[2];
         hook_hb = h - 1;  // half-block h - 1 is finished inside the GEMM of half-block h
-        gemm_groups<false, 0, KG>(afrag0 + (h & 1) * (HB * LD), bq, acc, af, parts, epi_hook);
+        gemm_groups<false, 0, KG, 2>(afrag0 + (h & 1) * (HB * LD), bq, acc, af, parts, epi_hook);
         park(h, acc);
         if (h < 4) stamp(17 + 4 * h);
-        load_consts(h);
+        if (h + 1 < H) load_consts(h);  // (the last half-block is finished by all eight waves, in another lane layout)
         phase_barrier();  // A(h)
         if (h < 4) stamp(18 + 4 * h);
     }
-    // the last half-block has no GEMM to ride in
     stamp(3);
-    epi_begin(H - 1);
-    epi_fetch(0);
-    epi_finish(0);
-    epi_fetch(1);
-    epi_finish(1);
-    epi_fetch(2);
-    epi_finish(2);
+    final_epilogue(H - 1);
     stamp(5);
     if (trace && lane == 0) trace[13] = wall_clock64();
 }
@@ -467,10 +515,9 @@ dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s) {
     const int dev = PerDeviceOnce::current();
     const size_t lds = flame_decode_pipe_lds_bytes();
     if (!attr_done.done(dev)) {
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_pipe_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DAD3D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&flame_decode_pipe_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_pipe_kernel<true>),
+                              reinterpret_cast<const void*>(&flame_decode_pipe_kernel<false>)})
+            DAD3D_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done.set(dev);
     }
     if (a.flags & DAD3D_TO_2D) hipLaunchKernelGGL(flame_decode_pipe_kernel<true>, dim3(a.n_tiles), dim3(512), lds, s, a);
