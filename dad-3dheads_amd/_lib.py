@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("DAD3D_LIB_PATH") or os.path.join(_HERE, "libdad3d_hip
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = range(5)
 ZERO_ROTATION, TO_2D, MUTATE_PARAMS, FLIP_Z, COMPAT_CROSS_B3 = 0x1, 0x2, 0x4, 0x8, 0x10
 NORMAL_ACCUMULATE = 0x1
+KERNEL_AUTO, KERNEL_TWO_ROLE, KERNEL_PIPELINED = 0, 1, 2
 
 
 class Dad3dError(RuntimeError):
@@ -82,6 +83,7 @@ SIGNATURES = {
     "dad3d_flame_readjust_params": (_I, [_P, _P, _I, _P, _F, _F, _F, _P]),
     "dad3d_flame_profile_begin": (_I, [_P, _P]),
     "dad3d_flame_profile_end": (_I, [_P, _P, C.POINTER(C.c_double), C.POINTER(_I)]),
+    "dad3d_flame_select_kernel": (_I, [_P, _I]),
     "dad3d_flame_handoff_timeouts": (_I, [_P, C.POINTER(C.c_uint)]),
     "dad3d_flame_debug_trace": (_I, [_P, _P]),
     "dad3d_mesh_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),

@@ -65,6 +65,7 @@ struct dad3d_flame {
     std::shared_ptr<FlameConsts> c;
     int *d_lmk_head = nullptr, *d_lmk_next = nullptr;
     float4* d_vtab = nullptr;  // [V] {W, w_jaw, first landmark slot, slot chained after it}: per handle (the landmark list is)
+    int kernel_choice = -1;    // dad3d_flame_select_kernel; -1 = the process default (DAD3D_DECODE_KERNEL)
     float* d_bwd_partials = nullptr;  // [cap][kBackwardMaxSplit][72] scratch of dad3d_flame_decode_backward
     int bwd_cap = 0;
     float* d_grad_partials = nullptr;  // [slices][padded batch][kGradRows] scratch of dad3d_flame_grad_inputs
@@ -80,13 +81,12 @@ struct dad3d_flame {
     int prof_launches = 0;
 };
 
-// Which decode kernel a launch takes: DAD3D_DECODE_KERNEL=v1 forces the two-role kernel of rounds 1-3, =pipe the pipelined
-// single-role kernel whenever the model is covered (diagnostics / A-B timing); default: pipe above 16 images.
+// Process-wide default of dad3d_flame_select_kernel: DAD3D_DECODE_KERNEL=v1 forces the two-role kernel of rounds 1-3 (A/B timing).
 static int decode_kernel_choice() {
     static const int choice = [] {
         const char* e = getenv("DAD3D_DECODE_KERNEL");
         if (!e) return 0;
-        return (e[0] == 'v' && e[1] == '1') ? 1 : (e[0] == 'p') ? 2 : 0;
+        return (e[0] == 'v' && e[1] == '1') ? DAD3D_KERNEL_TWO_ROLE : DAD3D_KERNEL_AUTO;  // "pipe" = the default
     }();
     return choice;
 }
@@ -456,10 +456,14 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     // The pipelined single-role kernel (flame_decode_pipe.hip) takes every inference launch of a covered model (jaw-only, the
     // dad_3dnet.yaml params layout, no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3, outputs below 2 GB); the two-role kernel of
     // rounds 1-3 keeps the rest and the training forward. profiles/r04_ab_decode.txt has both at every batch size.
-    const int choice = decode_kernel_choice();
+    const int choice = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
-    if (pipe_covers && choice != 1) {
+    if (choice == DAD3D_KERNEL_PIPELINED && !pipe_covers) {
+        set_error("dad3d_flame_decode: the pipelined kernel does not cover this launch (model, flags or output size)");
+        return DAD3D_E_UNSUPPORTED;
+    }
+    if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE) {
         PipeArgs pa{};
         pa.params = params;
         pa.bpack = h->c->d_bpack_pipe;
@@ -594,6 +598,12 @@ dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batc
     DeviceGuard guard(h->device);
     return launch_readjust(params, batch, h->lay, pads_scale, pad_left, pad_top, scale, h->image_size,
                            static_cast<hipStream_t>(stream));
+}
+
+dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which) {
+    DAD3D_REQUIRE(h && which >= DAD3D_KERNEL_AUTO && which <= DAD3D_KERNEL_PIPELINED, "dad3d_flame_select_kernel: bad argument");
+    h->kernel_choice = which;
+    return DAD3D_OK;
 }
 
 dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count) {

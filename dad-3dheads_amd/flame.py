@@ -195,6 +195,12 @@ class FLAMELayer(torch.nn.Module):
         twin.__dict__["_handle"] = handle
         return twin
 
+    def select_kernel(self, which: str = "auto") -> None:
+        """Diagnostics / A-B timing: "auto" (default: the pipelined single-role kernel wherever it covers the launch), "two_role"
+        (the kernel of rounds 1-3) or "pipelined" (raise instead of falling back). dad3d_flame_select_kernel."""
+        code = {"auto": _lib.KERNEL_AUTO, "two_role": _lib.KERNEL_TWO_ROLE, "pipelined": _lib.KERNEL_PIPELINED}[which]
+        _lib.check(self._lib.dad3d_flame_select_kernel(self._handle, code))
+
     def decode_tables(self):
         """Device tensors of the backward pass (autograd.DecodeTables), built on first use and shared with forks."""
         t = self.__dict__.get("_decode_tables")

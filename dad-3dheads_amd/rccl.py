@@ -14,10 +14,15 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 from typing import Optional
 
-import torch
+# dmabuf IPC only on this pool's host driver. Set when this module is imported -- before the first RCCL call of the process; a
+# process that needs it for torch's own nccl backend has to export it before HIP initialises (bench.py's self-launch does).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 _NCCL_CHAR = 0  # ncclInt8 / ncclChar
 
@@ -61,7 +66,6 @@ class RcclAllGather:
             raise RuntimeError("RcclAllGather needs an initialised torch.distributed group to hand out the unique id")
         if not torch.cuda.is_available():
             raise RuntimeError("RcclAllGather needs a GPU")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool's host driver
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.comm = C.c_void_p()
         # Every rank must enter ncclCommInitRank or none: a rank that cannot even load the library would leave the others
@@ -74,15 +78,35 @@ class RcclAllGather:
         dist.all_gather_object(errs, err, group=group)
         if any(errs):
             raise RuntimeError("RcclAllGather: librccl.so unusable on " + "; ".join(e for e in errs if e))
+        # The unique id travels as a (status, bytes) pair: a rank 0 whose ncclGetUniqueId failed still takes part in the broadcast,
+        # so its failure reaches every rank instead of leaving them in the broadcast for ever.
         uid = _UniqueId()
+        box = [None]
         if self.rank == 0:
-            _check(self.lib, self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]
+            status = self.lib.ncclGetUniqueId(C.byref(uid))
+            box = [(status, C.string_at(C.byref(uid), 128) if status == 0 else b"")]
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)
-        if not isinstance(box[0], bytes) or len(box[0]) != 128:
-            raise RuntimeError("RcclAllGather: the unique id did not arrive")
-        C.memmove(C.byref(uid), box[0], 128)
+        status, raw = box[0] if isinstance(box[0], tuple) and len(box[0]) == 2 else (-1, b"")
+        if status != 0 or not isinstance(raw, bytes) or len(raw) != 128:
+            raise RuntimeError(f"RcclAllGather: rank 0 could not produce a unique id (ncclGetUniqueId status {status})")
+        C.memmove(C.byref(uid), raw, 128)
+        self._rendezvous(uid, init_timeout_s)
+
+    @classmethod
+    def solo(cls, init_timeout_s: float = 120.0) -> "RcclAllGather":
+        """A communicator of ONE rank on the current device, no torch.distributed needed: the N = 1 point of a scaling run then
+        executes the same collective call as N = 8 (bench.py without a launcher)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("RcclAllGather needs a GPU")
+        self = object.__new__(cls)
+        self.world, self.rank, self.comm, self.lib = 1, 0, C.c_void_p(), _load()
+        uid = _UniqueId()
+        _check(self.lib, self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        self._rendezvous(uid, init_timeout_s)
+        return self
+
+    def _rendezvous(self, uid, init_timeout_s: float) -> None:
         # The rendezvous itself runs on a helper thread with a deadline (ctypes releases the GIL): a bootstrap that never
         # completes must surface as an error the caller can fall back from, not as a hung job. The thread needs the rank's
         # device selected -- the communicator binds to the calling thread's current device.
@@ -122,6 +146,8 @@ class RcclAllGather:
             self.comm = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():  # HIP / RCCL may already be gone: a native crash there is not an exception
+            return
         try:
             self.destroy()
         except Exception:

@@ -175,6 +175,15 @@ dad3d_status dad3d_flame_profile_end(dad3d_flame* h, void* stream, double* total
 /* How many decode workgroups ever gave up waiting for the pose role's hand-off and recomputed the per-image
  * constants themselves (still correct, slower). Expected 0; synchronises the device. */
 dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
+/* Which kernel a decode launch of this handle takes: DAD3D_KERNEL_AUTO (default) = the pipelined single-role kernel
+ * (csrc/flame_decode_pipe.hip) whenever it covers the launch -- jaw-only model with the dad_3dnet.yaml params layout, inference outputs,
+ * no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3 -- and the two-role kernel (csrc/flame_decode.hip) otherwise; DAD3D_KERNEL_TWO_ROLE
+ * forces the latter; DAD3D_KERNEL_PIPELINED returns DAD3D_E_UNSUPPORTED from a decode the pipelined kernel does not cover instead of
+ * falling back. The environment variable DAD3D_DECODE_KERNEL=v1|pipe sets the process-wide default (A/B timing). */
+#define DAD3D_KERNEL_AUTO 0
+#define DAD3D_KERNEL_TWO_ROLE 1
+#define DAD3D_KERNEL_PIPELINED 2
+dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which);
 /* Diagnostics: DEVICE buffer of [grid blocks][4 waves][32] uint64 that every wave of the fused kernel fills
  * with shader-clock stamps at its phase boundaries (start, loads issued, operands landed, GEMM done, tile
  * staged, end; slots 8.. = one per staging chunk); NULL switches it off. Grid blocks = 8*ceil(ceil(V/21)/8) * ceil(B/64). */

@@ -1,0 +1,121 @@
+"""GPU: the pipelined single-role decode kernel (csrc/flame_decode_pipe.hip, round 4) against the two-role kernel of rounds 1-3
+and the CPU oracle, through the C ABI. Both kernels restate model_training/model/flame.py:191-228 + smplx.lbs; the pipelined one
+drops the translations of the joints that cannot rotate (they cancel to fp32 rounding), so the two agree to ~1e-7, not bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from dad_3dheads_amd import _lib, landmarks, synthetic
+from dad_3dheads_amd.head_mesh import HeadMesh
+from oracle import flame_ref
+
+pytestmark = pytest.mark.gpu
+TOL_V, TOL_PX = 5e-6, 1e-3  # the bars of tests/test_gpu_decode.py (north star: 1e-4 abs)
+
+
+@pytest.fixture(scope="module")
+def meshes(flame_model, static):
+    lm = landmarks.canonical("445", static)
+    pipe = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
+    pipe.flame.select_kernel("pipelined")  # raises instead of falling back
+    two = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
+    two.flame.select_kernel("two_role")
+    return pipe, two
+
+
+# ragged and aligned batch sizes around every boundary of the 32-image half-blocks and the 128-image constants rounds
+@pytest.mark.parametrize("batch", [1, 3, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 127, 128, 129, 200, 259, 385])
+@pytest.mark.parametrize("to_2d", [True, False])
+def test_pipelined_kernel_agrees_with_the_two_role_kernel(meshes, static, batch, to_2d):
+    pipe, two = meshes
+    params = synthetic.synthetic_params(batch, seed=7000 + batch)
+    a_in, b_in = torch.from_numpy(params).cuda(), torch.from_numpy(params).cuda()
+    a = pipe.decode(a_in, to_2d=to_2d, landmarks=True, landmarks_px=True)
+    b = two.decode(b_in, to_2d=to_2d, landmarks=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a_in, b_in)  # tz := 0 written back by both, nothing else touched
+    assert float((a["verts3d"] - b["verts3d"]).abs().max()) < 1e-6
+    assert float((a["proj"] - b["proj"]).abs().max()) < 3e-4
+    lm = torch.from_numpy(landmarks.canonical("445", static)).cuda()
+    assert torch.equal(a["lmk_xy"], a["proj"][:, lm, :2])  # the gather is exact in both
+    assert torch.equal(a["lmk_px"], a["proj"][:, lm, :2].to(torch.int32))
+    d = (a["lmk_px"] - b["lmk_px"]).abs()
+    frac = (b["lmk_xy"] - torch.round(b["lmk_xy"])).abs()
+    assert bool(((d == 0) | ((d == 1) & (frac < 1e-3))).all())
+
+
+@pytest.mark.parametrize("batch", [32, 64, 70, 256])
+def test_pipelined_kernel_matches_oracle_with_every_flag(meshes, flame_consts, batch):
+    pipe, _ = meshes
+    params = synthetic.synthetic_params(batch, seed=7100 + batch)
+    p = torch.from_numpy(params.copy())
+    v_ref = flame_ref.vertices_3d(flame_consts, p).numpy()
+    p3_ref = flame_ref.reprojected_vertices(flame_consts, p, to_2d=False).numpy()
+    out = pipe.decode(torch.from_numpy(params).cuda(), to_2d=False, flip_z=True)
+    only_v = pipe.decode(torch.from_numpy(params).cuda(), proj=False, landmarks=False)  # a null output pointer
+    only_p = pipe.decode(torch.from_numpy(params).cuda(), verts3d=False, to_2d=True, landmarks=False)
+    torch.cuda.synchronize()
+    assert np.abs(out["verts3d"].cpu().numpy() - v_ref).max() < TOL_V
+    flipped = p3_ref.copy()
+    flipped[..., 2] *= -1.0  # inference/pncc_estimator.py:88
+    assert np.abs(out["proj"].cpu().numpy() - flipped).max() < TOL_PX
+    assert np.abs(only_v["verts3d"].cpu().numpy() - v_ref).max() < TOL_V
+    assert np.abs(only_p["proj"].cpu().numpy() - p3_ref[..., :2]).max() < TOL_PX
+
+
+def test_duplicate_rows_are_bit_identical_wherever_they_land(meshes):
+    """The same params row in different half-blocks, constants rounds and lanes decodes to the same bits (the epilogue and the
+    constants code are inlined at several places; they are compiled without fp contraction and with explicit FMAs)."""
+    pipe, _ = meshes
+    base = synthetic.synthetic_params(5, seed=7200)
+    idx = np.array([0, 1, 2, 3, 4] * 60 + [2, 0])  # 302 rows: 10 half-blocks, 3 rounds, ragged end
+    out = pipe.decode(torch.from_numpy(base[idx]).cuda(), to_2d=True, landmarks=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    for k in ("verts3d", "proj", "lmk_xy", "lmk_px"):
+        t = out[k]
+        for r in range(5):
+            rows = t[torch.from_numpy(np.nonzero(idx == r)[0]).cuda()]
+            assert torch.equal(rows, rows[:1].expand_as(rows)), (k, r)
+
+
+def test_unsupported_launches_fall_back_or_refuse(flame_model, static, flame_consts):
+    lm = landmarks.canonical("445", static)
+    auto = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
+    params = synthetic.synthetic_params(40, seed=7300)
+    z = auto.decode(torch.from_numpy(params).cuda(), proj=False, landmarks=False, zero_rotation=True)["verts3d"]  # two-role kernel
+    torch.cuda.synchronize()
+    ref = flame_ref.vertices_3d(flame_consts, torch.from_numpy(params.copy()), zero_rotation=True).numpy()
+    assert np.abs(z.cpu().numpy() - ref).max() < TOL_V
+    auto.flame.select_kernel("pipelined")
+    with pytest.raises(_lib.UnsupportedError):
+        auto.decode(torch.from_numpy(params).cuda(), proj=False, landmarks=False, zero_rotation=True)
+
+
+def test_back_to_back_launches_of_changing_sizes_and_a_graph_replay(meshes, flame_consts):
+    """The kernel keeps no state between launches (no hand-off buffer, no counters): sizes can change from launch to launch,
+    and a captured launch replays (nothing per-launch comes from the host)."""
+    pipe, _ = meshes
+    sizes = [64, 1, 33, 256, 17, 130, 64]
+    ins = [torch.from_numpy(synthetic.synthetic_params(b, seed=7400 + i)).cuda() for i, b in enumerate(sizes)]
+    outs = [pipe.decode(x, to_2d=True, landmarks_px=True) for x in ins]
+    torch.cuda.synchronize()
+    for x, o in zip(ins, outs):
+        v_ref = flame_ref.vertices_3d(flame_consts, x.cpu().clone()).numpy()
+        assert np.abs(o["verts3d"].cpu().numpy() - v_ref).max() < TOL_V
+    p = torch.from_numpy(synthetic.synthetic_params(96, seed=7500)).cuda()
+    bufs = {k: torch.empty(s, dtype=dt, device="cuda") for k, s, dt in (("verts3d", (96, 5023, 3), torch.float32),
+                                                                          ("proj", (96, 5023, 2), torch.float32))}
+    eager = pipe.decode(p.clone(), to_2d=True, landmarks=False)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pipe.decode(p, to_2d=True, landmarks=False, out=bufs)  # warm-up on the capture stream
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            pipe.decode(p, to_2d=True, landmarks=False, out=bufs)
+        for k in bufs:
+            bufs[k].zero_()
+        g.replay()
+        s.synchronize()
+    for k in bufs:
+        assert torch.equal(bufs[k], eager[k]), k

@@ -177,12 +177,40 @@ def test_bench_plain_and_torchrun_lines_agree_and_two_gpus_are_refused():
     for d in (a, s, b):
         assert d["config"]["outputs_verified"] is True and d["config"]["handoff_timeouts"] == 0 and d["n_gpus"] == 1
         assert d["roofline"]["frac"] > 0.3 and d["unit"] == "images/sec"
+        # every line runs the job's one collective behind its K steps and prints both per-step times
+        assert d["config"]["gather_via"] is not None and d["ms_per_step_with_gather"] >= d["ms_per_step_compute"] > 0
+    assert "compute" in a["config"]["value_definition"] and "with_gather" in b["config"]["value_definition"]
+    assert abs(a["ms_per_step"] - a["ms_per_step_compute"]) < 1e-9 and abs(b["ms_per_step"] - b["ms_per_step_with_gather"]) < 1e-9
     assert "nccl" in b["config"]["parallelism"] and "no process group" in a["config"]["parallelism"]
     assert abs(a["value"] - b["value"]) / a["value"] < 0.10, (a["value"], b["value"])
     assert abs(a["value"] - s["value"]) / a["value"] < 0.05, (a["value"], s["value"])
     if torch.cuda.device_count() < 2:
         two = _run_bench(base + ["--gpus", "2", "--steps", "5", "--warmup", "1"], timeout=120)
         assert two.returncode != 0 and "2 GPUs requested, 1 visible" in two.stderr, two.stderr[-500:]
+
+
+def test_bench_eight_ranks_code_path_on_one_gpu():
+    """The N = 8 code path of bench.py before an 8-GPU node ever sees it: eight ranks under torch.distributed.run sharing the one
+    GPU (DAD3D_BENCH_SHARE_GPU=1: gloo, host-staged gathers), both workloads -- per-rank seeds, MAX over ranks, the gather of
+    8 x 64 rows and its check, the two per-step times, clean teardown. Not a multi-GPU measurement, and the line says so."""
+    for workload, steps in (("decode", "100"), ("render", "20")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--gpus", "8", "--steps", steps,
+               "--warmup", "10", "--workload", workload]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
+        env["DAD3D_BENCH_SHARE_GPU"] = "1"
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-1500:]
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1  # rank 0 prints ONE JSON line
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak" and d["value"] > 0
+        if workload == "decode":
+            assert d["config"]["outputs_verified"] is True and "not a multi-GPU measurement" in d["config"]["parallelism"]
+            assert d["ms_per_step_compute"] > 0 and d["ms_per_step_with_gather"] >= d["ms_per_step_compute"]
+            assert "with_gather" in d["config"]["value_definition"]
+        else:
+            assert d["config"]["gather_verified"] is True and d["config"]["images_with_coverage"] == 1.0
 
 
 def test_bench_two_ranks_code_path_on_one_gpu():

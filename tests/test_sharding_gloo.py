@@ -109,6 +109,44 @@ def test_gather_rows_uint8_images_two_ranks(tmp_path):
             assert got.dtype == np.uint8 and np.array_equal(got, ref), (n, r)
 
 
+def _pattern_rows(lo, hi):
+    """int32 landmark-shaped rows [hi - lo, 445, 2] whose content is a function of the GLOBAL row index."""
+    rows = torch.arange(lo, hi, dtype=torch.int64)
+    return ((rows[:, None, None] * 131 + torch.arange(445)[None, :, None] * 7 + torch.arange(2)[None, None, :]) % 65521).to(torch.int32)
+
+
+def _world8_worker(rank, world, port, n_list, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for n in n_list:
+            lo, hi = sharding.shard_range(n, rank, world)
+            full = sharding.gather_rows(_pattern_rows(lo, hi).contiguous(), n)
+            ok = full.shape == (n, 445, 2) and bool(torch.equal(full, _pattern_rows(0, n)))
+            img = ((torch.arange(lo, hi)[:, None, None, None] * 5 + torch.arange(4)[None, :, None, None] * 3 +
+                    torch.arange(4)[None, None, :, None] + torch.arange(3)[None, None, None, :] * 2) % 251).to(torch.uint8)
+            full_img = sharding.gather_rows(img.contiguous(), n)
+            ref_img = ((torch.arange(0, n)[:, None, None, None] * 5 + torch.arange(4)[None, :, None, None] * 3 +
+                        torch.arange(4)[None, None, :, None] + torch.arange(3)[None, None, None, :] * 2) % 251).to(torch.uint8)
+            ok = ok and full_img.dtype == torch.uint8 and bool(torch.equal(full_img, ref_img))
+            with open(os.path.join(out_dir, f"w8_r{rank}_n{n}.txt"), "w") as f:
+                f.write("ok" if ok else "MISMATCH")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()  # clean teardown at world 8
+
+
+def test_gather_rows_world_of_eight_even_ragged_and_tiny(tmp_path):
+    """BASELINE configs[3] shape: 2048 rows over 8 ranks (256 each) -- and 2048 + 3 (ragged), 11 and 5 (fewer rows than ranks: three
+    ranks hold nothing). Landmark rows (int32) and uint8 images; every rank must end up with the whole batch in row order."""
+    n_list, world = [2048, 2051, 11, 5], 8
+    mp.spawn(_world8_worker, args=(world, _free_port(), n_list, str(tmp_path)), nprocs=world, join=True)
+    for n in n_list:
+        for r in range(world):
+            assert (tmp_path / f"w8_r{r}_n{n}.txt").read_text() == "ok", (n, r)
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` is what the driver runs: with fewer devices than N it must say so (not print a usage
     error, not hang in a rendezvous). This container has no GPU at all, so N = 2 is refused the same way."""
