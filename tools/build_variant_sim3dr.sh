@@ -8,5 +8,5 @@ H=/opt/rocm/bin/hipcc; C="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-
 mkdir -p "$root/tools/_variants"; tmp="$(mktemp -d)"; trap 'rm -rf "$tmp"' EXIT
 (cd "$S" && make -s)
 $H $C $flags -x hip -c "$src" -o "$tmp/s3.o"
-$H --offload-arch=gfx950 -shared -fPIC -o "$root/tools/_variants/lib_$name.so" "$tmp/s3.o" "$S/flame_decode.o" "$S/capi.o" "$S/flame_backward.o" "$S/projection.o" "$S/preprocess.o" "$S/mesh_losses.o" "$S/cnn_glue.o" "$S/sim3dr_compat.o"
+$H --offload-arch=gfx950 -shared -fPIC -o "$root/tools/_variants/lib_$name.so" "$tmp/s3.o" "$S/flame_decode.o" "$S/flame_decode_pipe.o" "$S/capi.o" "$S/flame_backward.o" "$S/projection.o" "$S/preprocess.o" "$S/mesh_losses.o" "$S/cnn_glue.o" "$S/sim3dr_compat.o"
 echo "built tools/_variants/lib_$name.so"
