@@ -453,9 +453,12 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         dad3d_status st = grad_inputs_prepare(h, batch, s);
         if (st) return st;
     }
-    // The pipelined single-role kernel (flame_decode_pipe.hip) takes every inference launch of a covered model (jaw-only, the
+    // The pipelined single-role kernel (flame_decode_pipe.hip) takes the inference launches of a covered model (jaw-only, the
     // dad_3dnet.yaml params layout, no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3, outputs below 2 GB); the two-role kernel of
-    // rounds 1-3 keeps the rest and the training forward. profiles/r04_ab_decode.txt has both at every batch size.
+    // rounds 1-3 keeps the rest, the training forward, and the two batch ranges where it measured ahead (profiles/r04_ab_decode.txt:
+    // 6.7 against 7.8 us for a single image -- its quarter-size instantiation --, 11.6 against 12.1 us at 33 images; 8.0 / 8.6 /
+    // 12.3 / 12.9 / 16.8 / 37.7 / 139 / 272 us against 8.4 / 11.4 / 12.2 / 12.8 / 22.3 / 42.4 / 158 / 324 at 16 / 32 / 48 / 64 /
+    // 96 / 256 / 1024 / 2048).
     const int choice = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
@@ -463,7 +466,8 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         set_error("dad3d_flame_decode: the pipelined kernel does not cover this launch (model, flags or output size)");
         return DAD3D_E_UNSUPPORTED;
     }
-    if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE) {
+    const bool two_role_ahead = batch <= 8 || (batch > kPipeHalf && batch < 48);
+    if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE && (choice == DAD3D_KERNEL_PIPELINED || !two_role_ahead)) {
         PipeArgs pa{};
         pa.params = params;
         pa.bpack = h->c->d_bpack_pipe;
@@ -955,18 +959,15 @@ dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* ve
                                   float* depth, int batch, int h, int w, int c, float alpha, int reverse,
                                   void* stream) {
     DAD3D_REQUIRE(m && batch >= 0 && h >= 0 && w >= 0 && c >= 0, "dad3d_mesh_rasterize: bad argument");
-    if (alpha != 1.0f) {
-        set_error("dad3d_mesh_rasterize: alpha=%g; only alpha == 1 is supported (the reference result for other "
-                  "values depends on triangle order)", (double)alpha);
-        return DAD3D_E_UNSUPPORTED;
-    }
+    DAD3D_REQUIRE(alpha == alpha, "dad3d_mesh_rasterize: alpha is NaN");
     if (batch == 0 || h == 0 || w == 0) return DAD3D_OK;
     DAD3D_REQUIRE(image && (vertices || m->ntri == 0) && (colors || m->ntri == 0 || c == 0),
                   "dad3d_mesh_rasterize: null buffer");
     DeviceGuard guard(m->device);
     if (dad3d_status st = m->raster_scratch(batch, h, w, static_cast<hipStream_t>(stream))) return st;
-    return launch_rasterize(m->dev(), m->nc, m->d_raster, m->d_trace, image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse, 0,
-                            nullptr, static_cast<hipStream_t>(stream));
+    // alpha != 1: the blends of rasterize_kernel.cpp:268-284 replayed in triangle order (mode 2)
+    return launch_rasterize(m->dev(), m->nc, m->d_raster, m->d_trace, image, vertices, colors, depth, nullptr, nullptr, batch, h, w, c, reverse,
+                            alpha == 1.0f ? 0 : 2, nullptr, static_cast<hipStream_t>(stream), alpha);
 }
 
 dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* vertices, float* light, float* depth, int batch,

@@ -246,7 +246,7 @@ size_t raster_scratch_bytes(const MeshDev& m, int batch, int h, int w);
 dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int h, int w, hipStream_t s);
 dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc, void* scratch, unsigned long long* trace, uint8_t* image, const float* vertices,
                               const float* colors, float* depth, int32_t* tri_buf, float* bary, int batch, int h,
-                              int w, int c, int render_flags, int mode, const dad3d_light* light_cfg, hipStream_t s);
+                              int w, int c, int render_flags, int mode, const dad3d_light* light_cfg, hipStream_t s, float alpha = 1.0f);
 dad3d_status launch_phong(const MeshDev& m, const NormalChunksDev* nc, float* light, const float* vertices, const float* normals,
                           float* normals_out, int batch, const dad3d_light& cfg, hipStream_t s);
 

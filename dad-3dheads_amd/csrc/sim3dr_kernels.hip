@@ -1338,6 +1338,138 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     }
 }
 
+// _rasterize with alpha != 1 (rasterize_kernel.cpp:268-284). The reference walks the triangles in index order and blends every
+// fragment that passes the running depth test into the pixel: (unsigned char)((1 - alpha) * old + alpha * 255 * colour), then
+// raises the pixel's depth. Per pixel that is a CHAIN: the fragments that are records (strictly deeper than everything before
+// them) of the depth sequence in triangle order. It is replayed exactly, one link per pass: every pass walks the item's triangles
+// and keeps, per pixel, the LOWEST triangle index among the fragments that are deeper than the pixel's current depth and come
+// after its last blended triangle (ds_min_u64 on index << 32 | orderable depth); the winners are blended in a resolve step, and
+// the passes stop when no pixel found a successor. A head mesh has two to four layers, so a handful of passes -- this path is
+// unreachable from the reference's Python (Sim3DR.py:27-28 passes alpha = 1) and exists for the boundary's sake; it reuses the
+// geometry kernel's records, tile lists and work queue. One lane per triangle, 1 to 4 channels.
+__global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs a, float alpha) {
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[kTile * kTile];   // candidate of this pass: tri << 32 | depth
+    __shared__ __attribute__((aligned(16))) unsigned long long state[kTile * kTile];  // next admissible triangle << 32 | depth so far
+    __shared__ unsigned pixw[kTile * kTile];                                          // the pixel's bytes so far
+    __shared__ int s_any;
+    __shared__ unsigned s_next;
+    const int tid = threadIdx.x;
+    const int ntiles = a.sc.tiles_x * a.sc.tiles_y;
+    const size_t nt = a.m.ntri;
+    const unsigned n_items = a.sc.qhdr[0];
+    const int nc = a.c;
+    unsigned item = blockIdx.x;
+    while (item < n_items) {
+        const uint2 qe = a.sc.queue[item];
+        const int level = (qe.x >> 24) & 3, part = qe.x >> 26, n_total = (int)qe.y;
+        const size_t b = (qe.x & 0xFFFFFFu) / ntiles;
+        const int tile = (qe.x & 0xFFFFFFu) % ntiles;
+        const int edge = kTile >> level;
+        const int tx0 = (tile % a.sc.tiles_x) * kTile + (part & ((1 << level) - 1)) * edge;
+        const int ty0 = (tile / a.sc.tiles_x) * kTile + (part >> level) * edge;
+        const int tw = min(edge, a.w - tx0), th = min(edge, a.h - ty0);
+        const int tx1 = tx0 + tw - 1, ty1 = ty0 + th - 1;
+        const float3u* rec_b = a.sc.rec + b * nt;
+        const float* vb = a.vertices + b * a.m.nver * 3;
+        const float* cb = a.colors + b * a.m.nver * nc;
+        const unsigned* glist = a.sc.lists + (b * ntiles + tile) * nt;
+        float* depth_b = a.depth ? a.depth + b * a.h * a.w : nullptr;
+        uint8_t* img_b = a.image + b * (size_t)a.h * a.w * nc;
+        auto image_row = [&](int gy) { return a.reverse ? (a.h - 1 - gy) : gy; };
+        if (tw > 0 && th > 0) {
+            for (int p = tid; p < edge * th; p += kRasterThreads) {
+                const int ly = p / edge, lx = p % edge;
+                if (lx >= tw) continue;
+                const float z0 = depth_b ? depth_b[(size_t)(ty0 + ly) * a.w + tx0 + lx] : -1e8f;  // Sim3DR.py:23
+                state[ly * kTile + lx] = depth_order(z0);  // next admissible triangle: 0
+                const uint8_t* px = img_b + ((size_t)image_row(ty0 + ly) * a.w + tx0 + lx) * nc;
+                unsigned wv = 0;
+                for (int ch = 0; ch < nc; ++ch) wv |= (unsigned)px[ch] << (8 * ch);
+                pixw[ly * kTile + lx] = wv;
+            }
+            for (;;) {
+                for (int p = tid; p < kTile * th; p += kRasterThreads) keys[p] = ~0ull;
+                if (tid == 0) s_any = 0;
+                __syncthreads();
+                for (int i = tid; i < n_total; i += kRasterThreads) {
+                    const unsigned f = glist[i] & kIdMask;
+                    const float3u rc = rec_b[f];
+                    const unsigned bbx = __float_as_uint(rc.y), bby = __float_as_uint(rc.z);
+                    const int x0 = max((int)(bbx & 0xffff), tx0), x1 = min((int)(bbx >> 16), tx1);
+                    const int y0 = max((int)(bby & 0xffff), ty0), y1 = min((int)(bby >> 16), ty1);
+                    if (x1 < x0 || y1 < y0) continue;
+                    const int i0 = a.m.tri[3 * (size_t)f], i1 = a.m.tri[3 * (size_t)f + 1], i2 = a.m.tri[3 * (size_t)f + 2];
+                    const TriSetup ts = setup_from_corners(vb[3 * i0], vb[3 * i0 + 1], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i2], vb[3 * i2 + 1], rc.x);
+                    const float z0 = vb[3 * i0 + 2], z1 = vb[3 * i1 + 2], z2 = vb[3 * i2 + 2];
+                    for (int y = y0; y <= y1; ++y)
+                        for (int x = x0; x <= x1; ++x) {
+                            float u, v;
+                            tri_uv(ts, (float)x, (float)y, u, v);
+                            const float w0 = 1.0f - u - v;
+                            if (!(u > 0.0f && v > 0.0f && w0 > 0.0f)) continue;
+                            const float z = w0 * z0 + v * z1 + u * z2;
+                            if (z != z) continue;  // NaN never passes `>`
+                            const int slot = (y - ty0) * kTile + (x - tx0);
+                            const unsigned long long st = state[slot];
+                            const unsigned dk = depth_order_number(z);
+                            if (dk > (unsigned)st && f >= (unsigned)(st >> 32))
+                                (void)__hip_atomic_fetch_min(&keys[slot], ((unsigned long long)f << 32) | dk, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                }
+                __syncthreads();
+                bool any = false;
+                for (int p = tid; p < edge * th; p += kRasterThreads) {
+                    const int ly = p / edge, lx = p % edge;
+                    if (lx >= tw) continue;
+                    const int slot = ly * kTile + lx;
+                    const unsigned long long k = keys[slot];
+                    if (k == ~0ull) continue;
+                    any = true;
+                    const unsigned f = (unsigned)(k >> 32);
+                    const int i0 = a.m.tri[3 * (size_t)f], i1 = a.m.tri[3 * (size_t)f + 1], i2 = a.m.tri[3 * (size_t)f + 2];
+                    const TriSetup ts = setup_from_corners(vb[3 * i0], vb[3 * i0 + 1], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i2], vb[3 * i2 + 1],
+                                                           rec_b[f].x);
+                    float u, v;
+                    tri_uv(ts, (float)(tx0 + lx), (float)(ty0 + ly), u, v);
+                    const float w0 = 1.0f - u - v;
+                    unsigned wv = pixw[slot], out = 0;
+                    for (int ch = 0; ch < nc; ++ch) {
+                        const float cv = w0 * cb[nc * i0 + ch] + v * cb[nc * i1 + ch] + u * cb[nc * i2 + ch];
+                        const float old = (float)(int)((wv >> (8 * ch)) & 0xff);
+                        out |= (unsigned)(f2i_x86((1.0f - alpha) * old + alpha * 255.0f * cv) & 0xff) << (8 * ch);
+                    }
+                    pixw[slot] = out;
+                    state[slot] = ((unsigned long long)(f + 1) << 32) | (unsigned)k;
+                }
+                if (any) s_any = 1;
+                __syncthreads();
+                if (!s_any) break;
+                __syncthreads();  // everybody has read s_any before the next pass clears it
+            }
+            for (int p = tid; p < edge * th; p += kRasterThreads) {
+                const int ly = p / edge, lx = p % edge;
+                if (lx >= tw) continue;
+                const int slot = ly * kTile + lx;
+                const unsigned long long st = state[slot];
+                if ((st >> 32) == 0) continue;  // no fragment passed: the pixel and its depth stay untouched
+                const unsigned wv = pixw[slot];
+                uint8_t* px = img_b + ((size_t)image_row(ty0 + ly) * a.w + tx0 + lx) * nc;
+                for (int ch = 0; ch < nc; ++ch) px[ch] = (uint8_t)((wv >> (8 * ch)) & 0xff);
+                if (depth_b) {  // inverse of the orderable mapping (a depth of -0 is stored as +0: equal as floats)
+                    const unsigned dk = (unsigned)st;
+                    depth_b[(size_t)(ty0 + ly) * a.w + tx0 + lx] = __uint_as_float((dk & 0x80000000u) ? (dk & 0x7fffffffu) : ~dk);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_next = gridDim.x + atomicAdd(&a.sc.qhdr[1], 1u);
+        __syncthreads();
+        item = s_next;
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1456,8 +1588,9 @@ dad3d_status raster_scratch_init(const MeshDev& m, void* scratch, int batch, int
 dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc_all, void* scratch, unsigned long long* trace, uint8_t* image,
                               const float* vertices, const float* colors, float* depth, int32_t* tri_buf, float* bary,
                               int batch, int h, int w, int c, int render_flags, int mode, const dad3d_light* light_cfg,
-                              hipStream_t s) {
+                              hipStream_t s, float alpha) {
     const int reverse = render_flags & DAD3D_RENDER_REVERSE;
+    DAD3D_REQUIRE(mode != 2 || (c >= 1 && c <= 4), "rasterize with alpha != 1: 1 to 4 channels, got %d", c);
     if (batch == 0 || h == 0 || w == 0 || m.ntri == 0) return DAD3D_OK;  // nothing to draw: buffers stay as they are
     const size_t nlists = (size_t)batch * tiles_of(h) * tiles_of(w);
     DAD3D_REQUIRE(h <= 65535 && w <= 65535 && tiles_of(h) * tiles_of(w) <= kMaxTiles && nlists < (1u << 24),
@@ -1536,8 +1669,11 @@ dad3d_status launch_rasterize(const MeshDev& m, const NormalChunksDev* nc_all, v
     const int blocks = (int)std::min<size_t>(persistent_blocks[mode ? 1 : 0], nlists * kMaxSubs);
     if (mode == 0)
         hipLaunchKernelGGL(raster_kernel<0>, dim3(blocks), dim3(kRasterThreads), 0, s, a);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL(raster_kernel<1>, dim3(blocks), dim3(kRasterThreads), 0, s, a);
+    else  // one workgroup per CU: 80 KB of LDS
+        hipLaunchKernelGGL(raster_blend_kernel, dim3(std::min<size_t>(persistent_blocks[0] / 2 + 1, nlists * kMaxSubs)), dim3(kRasterThreads), 0, s,
+                           a, alpha);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

@@ -172,12 +172,7 @@ def test_render_pipeline_matches_numpy_lighting(static, decode_golden, sim3dr_or
         assert np.array_equal(pipe, ref_e), e  # RenderPipeline bytes bit-exact when pow is out of the picture
 
 
-def test_unsupported_alpha_and_empty_inputs():
-    mesh = Mesh(np.array([[0, 1, 2]], np.int32), 3, device=0)
-    v = torch.zeros((1, 3, 3), device="cuda")
-    img = torch.zeros((1, 4, 4, 3), dtype=torch.uint8, device="cuda")
-    with pytest.raises(_lib.UnsupportedError, match="alpha"):
-        mesh.rasterize(v, torch.zeros((1, 3, 3), device="cuda"), img, alpha=0.5)
+def test_empty_inputs():  # (alpha != 1: tests/test_gpu_raster_alpha.py)
     empty = Mesh(np.zeros((0, 3), np.int32), 4, device=0)
     out = empty.rasterize(torch.zeros((2, 4, 3), device="cuda"), torch.zeros((2, 4, 3), device="cuda"),
                           torch.full((2, 5, 5, 3), 3, dtype=torch.uint8, device="cuda"))

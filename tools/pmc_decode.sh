@@ -4,7 +4,7 @@
 # per-launch summary json under gpurun_out/pmc_decode/; the json is what profiles/r01_pmc_*.json are built from.
 export TMPDIR=/tmp; cd /tmp
 root="${GRAFT_REPO_ROOT:-/root/repo}"
-out="$root/gpurun_out/pmc_decode"; mkdir -p "$out"
+out="${PMC_OUT:-$root/gpurun_out/pmc_decode}"; mkdir -p "$out"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -21,7 +21,7 @@ import collections, csv, glob, json, sys
 acc, dur, name = collections.defaultdict(list), [], None
 for path in sorted(glob.glob(sys.argv[1] + "/set*.csv")):
     for r in csv.DictReader(open(path)):
-        if "flame_decode_kernel" not in r["Kernel_Name"]:
+        if "flame_decode" not in r["Kernel_Name"] or "readjust" in r["Kernel_Name"]:
             continue
         name = r["Kernel_Name"]
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
