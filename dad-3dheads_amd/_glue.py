@@ -49,6 +49,9 @@ def resize_sum(weights: Sequence[float], xs: Sequence[Tensor], size) -> Tensor:
     if not (1 <= k <= 3 and len(weights) == k):
         raise ValueError("resize_sum: one to three weighted inputs")
     x0 = xs[0]
+    if not supported(x0, *xs[1:]) or any(x.dim() != 4 or x.shape[0] != x0.shape[0] for x in xs):
+        raise ValueError("resize_sum: every input must be a channels-last CUDA tensor of one dtype, device, batch and channel count, "
+                         "16-byte aligned (the kernel reads raw NHWC rows)")
     n, c = x0.shape[0], x0.shape[1]
     oh, ow = int(size[0]), int(size[1])
     out = torch.empty((n, c, oh, ow), dtype=x0.dtype, device=x0.device, memory_format=torch.channels_last)

@@ -443,6 +443,9 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     if (batch == 0) return DAD3D_OK;
     DAD3D_REQUIRE(params, "dad3d_flame_decode: null params");  // `assert tensor_3dmm.ndim == 2` lives in the binding
     DAD3D_REQUIRE(!((flags & DAD3D_FLIP_Z) && (flags & DAD3D_TO_2D)), "DAD3D_FLIP_Z needs a 3-component projection");
+    // the batch-axis cross product exists in the inference forward only: its backward pass (flame_backward.hip) differentiates
+    // the per-image Gram-Schmidt rotation, so a training forward with the flag would get gradients of another function
+    DAD3D_REQUIRE(!(posed && (flags & DAD3D_COMPAT_CROSS_B3)), "DAD3D_COMPAT_CROSS_B3 is inference-only (dad3d_flame_decode_posed refuses it)");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // A training forward: what its backward pass needs exists before any of it can be captured into a graph -- for the batches
@@ -633,6 +636,9 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
     DAD3D_REQUIRE(consts && posed && grad_posed && grad_consts, "dad3d_flame_decode_backward: null argument");
     DAD3D_REQUIRE(grad_verts3d || grad_proj, "dad3d_flame_decode_backward: no upstream gradient");
     DAD3D_REQUIRE(!((flags & DAD3D_FLIP_Z) && (flags & DAD3D_TO_2D)), "DAD3D_FLIP_Z needs a 3-component projection");
+    // the batch-axis cross product exists in the inference forward only: its backward pass (flame_backward.hip) differentiates
+    // the per-image Gram-Schmidt rotation, so a training forward with the flag would get gradients of another function
+    DAD3D_REQUIRE(!(posed && (flags & DAD3D_COMPAT_CROSS_B3)), "DAD3D_COMPAT_CROSS_B3 is inference-only (dad3d_flame_decode_posed refuses it)");
     DeviceGuard guard(h->device);
     BackwardArgs ba{};
     ba.weights8 = h->c->d_w8;

@@ -1014,6 +1014,14 @@ static dad3d_status launch_decode_t(const DecodeArgs& a, hipStream_t s) {
 }
 
 dad3d_status launch_flame_decode(const DecodeArgs& a, hipStream_t s) {
+#if DAD3D_MFMA32
+    // diagnostics variant: capi.cpp packs the basis for the 32x32x2 tiling ONLY; the quarter-size instantiation (<= 16 images), the
+    // training forward and the backward pass's basis^T pack all read the 16x16x4 layout
+    if (a.posed || a.batch <= 16) {
+        set_error("DAD3D_MFMA32 build: only inference launches of more than 16 images");
+        return DAD3D_E_UNSUPPORTED;
+    }
+#endif
     switch (a.kgroups) {
         case 26:  // K = 400 + 9 (jaw only) + 1 -> 416
             return a.betas_contiguous ? launch_decode_t<26, true, true>(a, s) : launch_decode_t<26, true, false>(a, s);

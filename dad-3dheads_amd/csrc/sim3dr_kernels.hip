@@ -31,6 +31,9 @@
 #define DAD3D_NT_ABLATE 0
 #endif
 
+#ifndef DAD3D_PHONG_POWF  // 1: the specular term through powf for every exponent (parity checks against a host whose np.power goes
+#define DAD3D_PHONG_POWF 0  // through libm's powf); 0: small integer exponents as a product chain (within an ulp, not the same last bit)
+#endif
 namespace dad3d {
 namespace {
 
@@ -460,7 +463,7 @@ __device__ __forceinline__ void phong_light_chunk(const MeshDev& m, const Normal
                 float pw;
                 if (cfg.specular_exp == 2.0f) pw = t * t;
                 else if (cfg.specular_exp == 1.0f) pw = t;
-                else if (small_int_exp) {
+                else if (small_int_exp && !DAD3D_PHONG_POWF) {
                     float base = t;
                     pw = 1.0f;
                     for (int ee = int_exp; ee; ee >>= 1) {
@@ -553,7 +556,8 @@ constexpr int kListCap = 8 * kRasterThreads;  // list entries sorted per round (
 constexpr int kListPerThread = kListCap / kRasterThreads;
 constexpr int kClasses = 12;         // box area <=2, <=4, <=8, <=16, ... <=4096 (= a whole tile)
 constexpr int kSpread = 16;          // copies of every class counter: 64 lanes hit 16 addresses instead of one
-// One 12-byte record per (image, on-screen triangle): inv of get_point_weight's pixel-independent half and the screen box
+// One record of 12 bytes per (image, on-screen triangle), stored at a 16-byte stride (a three-float vector type is padded to 16
+// bytes; ScratchLayout sizes the array with sizeof): inv of get_point_weight's pixel-independent half and the screen box
 // exactly as rasterize_kernel.cpp:246-254 clips it (x0 | x1 << 16, y0 | y1 << 16). Rounds 1-2 kept a 48-byte record
 // (corner, edge vectors, inv, depths, box): 24-30 MB written by the geometry kernel and read back by the tile kernel, the
 // largest cost of the former. Everything but inv and the box is a few subtractions away from the three corners, which the

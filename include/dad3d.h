@@ -72,7 +72,8 @@ typedef struct dad3d_flame dad3d_flame; /* opaque: packed basis + scratch reside
                                     `dim`; for a batch of EXACTLY three rows torch's legacy rule takes the first axis of size
                                     3 -- the batch axis -- so the three images' 6-DoF rotations mix. With this flag a batch of
                                     three reproduces that (every other batch size is unaffected); without it (default) every
-                                    image gets its own Gram-Schmidt rotation, as for any other batch size */
+                                    image gets its own Gram-Schmidt rotation, as for any other batch size. INFERENCE ONLY:
+                                    dad3d_flame_decode_posed refuses it (the backward pass differentiates the per-image rotation) */
 
 /* Upload + repack the model for `device`. Replaces FLAMELayer.__init__ (flame.py:124-180) and
  * HeadMesh.__init__ (head_mesh.py:10-22). `image_size` is HeadMesh._image_size (256). */

@@ -3,9 +3,9 @@
 
     python tools/trace_pipe.py [batch]
 
-Per wave: 0 start | 1 constants round 0 written (mma) / first loads issued (stager) | 5 end | 12, 13 wall clock (100 MHz);
-first four half-blocks h: 16+4h before the GEMM / phase start, 17+4h accumulators parked / A(h+1) written, 18+4h past the barrier /
-next loads issued, 19+4h half-block finished / past the barrier."""
+Per wave: 0 start | 1 first seven MFMA groups done (mma) / first loads issued (stager) | 4 constants round 0 written | 3 last barrier
+passed | 5 end | 12, 13 wall clock (100 MHz); first four half-blocks h: 16+4h before the GEMM / phase start, 17+4h accumulators
+parked / A(h+1) written, 18+4h past the barrier / next loads issued, 19+4h (stagers) past the barrier."""
 import os
 import sys
 
@@ -44,8 +44,9 @@ print(f"  first MFMA groups done {med(0, 1):.0f} / {med(3, 1):.0f}; constants ro
 for h in range(min(4, (batch + 31) // 32)):
     a = [med(0, 16 + 4 * h + k) for k in range(4)]
     b = [med(3, 16 + 4 * h + k) for k in range(4)]
-    print(f"  half-block {h}: GEMM start {a[0]:.0f}/{b[0]:.0f}  parked {a[1]:.0f}/{b[1]:.0f} (GEMM {a[1] - a[0]:.0f})  past barrier {a[2]:.0f}/{b[2]:.0f} (wait {a[2] - a[1]:.0f})  "
-          f"finished {a[3]:.0f}/{b[3]:.0f} (epilogue {a[3] - a[2]:.0f})")
+    print(f"  half-block {h}: GEMM start {a[0]:.0f}/{b[0]:.0f}  parked {a[1]:.0f}/{b[1]:.0f} (GEMM incl. the previous half-block's epilogue {a[1] - a[0]:.0f})  "
+          f"past barrier {a[2]:.0f}/{b[2]:.0f} (wait {a[2] - a[1]:.0f})")
+print(f"  last half-block finished by all eight waves: {med(0, 5) - med(0, 3):.0f} cycles")
 print("stager waves (wave 4 / wave 7):")
 print(f"  first loads issued {med(4, 1):.0f}; A(0) published {med(4, 2):.0f}; end {med(4, 5):.0f}")
 for h in range(min(4, (batch + 31) // 32)):
