@@ -119,3 +119,23 @@ def test_back_to_back_launches_of_changing_sizes_and_a_graph_replay(meshes, flam
         s.synchronize()
     for k in bufs:
         assert torch.equal(bufs[k], eager[k]), k
+
+
+def test_duplicate_landmark_indices_the_565_list_and_a_forked_handle(flame_model, static):
+    """A vertex listed three times (the slot chain beyond the two slots a lane keeps in registers), the last vertex of the partial
+    last tile, a list swapped on a live handle (set_landmarks rewrites the per-vertex table), a fork with its own list."""
+    idx = np.array([5, 5, 0, 5022, 5, 17, 5021, 5020], dtype=np.int64)
+    hm = HeadMesh(flame_model=flame_model, landmarks=idx, static=static, device=0)
+    hm.flame.select_kernel("pipelined")
+    p = torch.from_numpy(synthetic.synthetic_params(70, seed=7600)).cuda()
+    out = hm.decode(p.clone(), landmarks_px=True)
+    assert torch.equal(out["lmk_xy"], out["proj"][:, torch.from_numpy(idx).cuda()])
+    assert torch.equal(out["lmk_px"], out["lmk_xy"].to(torch.int32))
+    twin = hm.fork()  # shares the basis, owns its landmark table
+    hm.set_landmarks(landmarks.canonical("565", static))
+    out565 = hm.decode(p.clone())
+    assert out565["lmk_xy"].shape == (70, 565, 2)
+    assert torch.equal(out565["lmk_xy"], out565["proj"][:, torch.from_numpy(landmarks.canonical("565", static)).cuda()])
+    out_twin = twin.decode(p.clone())
+    assert out_twin["lmk_xy"].shape == (70, len(idx), 2) and torch.equal(out_twin["lmk_xy"], out["lmk_xy"])
+    assert torch.equal(out_twin["verts3d"], out["verts3d"])
