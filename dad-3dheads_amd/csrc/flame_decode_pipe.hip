@@ -268,25 +268,37 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     if (wave >= 4) {
         // =============================================== stager waves =====================================================
         if (DAD3D_PIPE_STAGER_PRIO) __builtin_amdgcn_s_setprio(DAD3D_PIPE_STAGER_PRIO);
-        const int fw = wave - 4, ht = tid - 256;
-        // thread copies the float4s (row srow, 32 j + 4 c4), j = 0..12, of the half-block's 32 params rows (params[:, 0:400] are
-        // the betas: shape 300 + expression 100, flame.py:192-200 with nothing to pad). Rows are 4-byte aligned (413 floats).
-        const int srow = ht >> 3, c4 = ht & 7;
+        const int fw = wave - 4;
+        // The half-block's 32 params rows x 400 betas (params[:, 0:400]: shape 300 + expression 100, flame.py:192-200 with nothing
+        // to pad) as three slabs of 128 k and one of 16: a wave request covers 512 contiguous bytes of each of TWO rows (lane >> 5
+        // picks the row), 10 cache lines -- eight rows x 128 bytes per request were 16, and the CU's one address unit is what the
+        // launch's first microsecond waits for. Rows are 4-byte aligned (413 floats). pre[4 s + jj]: slab s, rows 8 fw + 2 jj + {0, 1};
+        // pre[12]: k = 384..399 of the wave's eight rows (lanes 0..31).
+        const int lr = lane >> 5, lc = lane & 31;
         float4 pre[13];   // the thread's share of the NEXT A image, requested a phase ahead
+        float4 pre1[13];  // ... and of the launch's SECOND image, requested while the first is still in `pre`
         auto load_rows = [&](int hb, float4 (&dst)[13]) {
-            const float* prow = a.params + (size_t)min(hb * HB + srow, B - 1) * P;  // rows past the batch re-read its last row
+            const int r0 = hb * HB + 8 * fw;
+            const float* prow[4];
 #pragma unroll
-            for (int jj = 0; jj < 13; ++jj) {
-                const int kk = (32 * jj + 28 < kNumBeta) ? 32 * jj + 4 * c4 : min(32 * jj + 4 * c4, kNumBeta - 4);
-                const f4u v = *reinterpret_cast<const f4u*>(prow + kk);
-                dst[jj] = float4{v.x, v.y, v.z, v.w};
-            }
+            for (int jj = 0; jj < 4; ++jj) prow[jj] = a.params + (size_t)min(r0 + 2 * jj + lr, B - 1) * P + 4 * lc;  // rows past the batch re-read its last row
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f4u v = *reinterpret_cast<const f4u*>(prow[jj] + 128 * sl);
+                    dst[4 * sl + jj] = float4{v.x, v.y, v.z, v.w};
+                    __builtin_amdgcn_sched_barrier(0);  // slab by slab, as the GEMM will want them
+                }
+            const f4u v = *reinterpret_cast<const f4u*>(a.params + (size_t)min(r0 + (lc >> 2), B - 1) * P + 384 + 4 * (lane & 3));
+            dst[12] = float4{v.x, v.y, v.z, v.w};
         };
-        auto write_rows = [&](int hb, int j0, int j1, const float4 (&src)[13]) {  // slabs [j0, j1) of 32 k; MFMA groups [0,8) [8,16) [16,26) = slabs [0,4) [4,8) [8,13)
-            float* dst = abuf + (hb & 1) * (HB * LD) + srow * LD + 4 * c4;
+        auto write_rows = [&](int hb, int j0, int j1, const float4 (&src)[13]) {  // MFMA groups [0,8) [8,16) [16,26) = pre[0,4) [4,8) [8,13)
+            float* img = abuf + (hb & 1) * (HB * LD);
 #pragma unroll
-            for (int jj = 0; jj < 13; ++jj)
-                if (jj >= j0 && jj < j1 && 32 * jj + 4 * c4 < kNumBeta) *reinterpret_cast<float4*>(dst + 32 * jj) = src[jj];
+            for (int idx = 0; idx < 12; ++idx)
+                if (idx >= j0 && idx < j1) *reinterpret_cast<float4*>(img + (8 * fw + 2 * (idx & 3) + lr) * LD + 128 * (idx >> 2) + 4 * lc) = src[idx];
+            if (j1 == 13 && lane < 32) *reinterpret_cast<float4*>(img + (8 * fw + (lane >> 2)) * LD + 384 + 4 * (lane & 3)) = src[12];
         };
         auto load_a = [&](int hb) { load_rows(hb, pre); };
         auto write_a = [&](int hb, int j0, int j1) { write_rows(hb, j0, j1, pre); };
@@ -303,30 +315,38 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
             }
         };
         load_a(0);  // in flight before anything else happens in this workgroup
-        if (fw == 3 && lane < TV)  // the tile's rows of the vertex table, for the last half-block (read behind the last barrier)
-            vt_lds[lane] = v0 + lane < a.n_verts ? a.vtab[v0 + lane] : float4{0.f, 0.f, __int_as_float(-1), __int_as_float(-1)};
+        // (by every stager wave, from a clamped row: a branch around a load -- even a wave-uniform one -- ends in a wait for it)
+        const float4 vt_row = a.vtab[min(v0 + min(lane, TV - 1), a.n_verts - 1)];
         stamp(1);
-        phase_barrier();  // the arrival words are zero
+        // Nothing in front of this barrier waits for data: it only tells the mma waves that the first A image's requests are in the
+        // CU's load queue, ahead of the 104 KB of basis they are about to ask for.
+        phase_barrier();  // (and: the arrival words are zero)
+        stamp(6);
         write_a(0, 0, 4);
         arrive(parts, lane);
+        stamp(7);
+        // The second A image, NOW: a CU's requests come back in order, so what is asked for once the basis requests are queued comes
+        // back behind the whole basis stream -- asked for behind barrier B0 these rows arrived 1.5 k cycles after the mma waves had
+        // parked the first half-block. Here they interleave with the first basis requests and are back long before that. (In front of
+        // the first barrier they would hold the basis back: 13.1 against 12.8 us at B = 64.)
+        if (H > 1) load_rows(1, pre1);
         write_a(0, 4, 8);
         arrive(parts + 1, lane);
         write_a(0, 8, 13);
         arrive(parts + 2, lane);
+        // the tile's rows of the vertex table, for the last half-block (read behind the last barrier)
+        if (fw == 3 && lane < TV) vt_lds[lane] = vt_row;
         stamp(2);
         phase_barrier();  // B0: constants round 0 is in LDS
-        // (requested only now: a request issued while the CU's load queue is full of basis blocks its wave -- with these 13 in front
-        // of B0 the mma waves stood at that barrier for 2 k cycles -- and requested together with the first image, in front of the
-        // basis, they put the first MFMA 1.2 k cycles later: 13.1 against 12.8 us at B = 64)
-        if (H > 1) load_a(1);
 #pragma unroll 1
         for (int h = 0; h < H; ++h) {
             if (h < 4) stamp(16 + 4 * h);
             if (h + 1 < H) {
-                // phase 0 is the one phase whose writes the mma waves end up waiting for (the rows arrive behind the basis stream):
-                // issue them ahead of the MFMAs; everywhere else a stager instruction may wait for a gap
+                // phase 0: the rows have been here since the first thousands of cycles; written ahead of the MFMAs (the third image's
+                // requests below block this wave until the basis stream has drained)
                 if (h == 0) __builtin_amdgcn_s_setprio(2);
-                write_a(h + 1, 0, 13);
+                if (h == 0) write_rows(1, 0, 13, pre1);
+                else write_a(h + 1, 0, 13);
                 write_tail(h + 1);
                 if (h == 0) __builtin_amdgcn_s_setprio(DAD3D_PIPE_STAGER_PRIO);
             }
@@ -348,11 +368,12 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     // float4 at A[16 m + n][16 G + 4 q] of the row-major LDS image and its B operand the float4 packed for (G, w, lane).
     const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + ((size_t)tile * KG * 4 + wave) * 64 + lane;
     // -- constants of 128 images at a time (a "round"): lanes 0..31 of wave w take images 128 r + 32 w + lane ------------------
-    f4u raw0 = {}, raw1 = {}, raw2 = {};  // (kept in the loaded type: a copy would make the wave wait for the load on the spot)
+    f4u raw0 = {}, raw1 = {};  // (kept in the loaded type: a copy would make the wave wait for the load on the spot)
+    f3u raw2 = {};             // (three floats, not four with translation z along: the compiler recycles a loaded register nobody reads, and waits for the load to do so)
     float raw_scale = 0.f;
     auto load_raw = [&](int r) {  // params[400..412] of the row, a phase before they are needed
         const float* prow = a.params + (size_t)min(r * kRound + 32 * wave + (lane & 31), B - 1) * P + kNumBeta;
-        raw0 = *reinterpret_cast<const f4u*>(prow), raw1 = *reinterpret_cast<const f4u*>(prow + 4), raw2 = *reinterpret_cast<const f4u*>(prow + 8);
+        raw0 = *reinterpret_cast<const f4u*>(prow), raw1 = *reinterpret_cast<const f4u*>(prow + 4), raw2 = *reinterpret_cast<const f3u*>(prow + 8);
         raw_scale = prow[12];
     };
     auto write_round = [&](int r, bool first) {
@@ -385,10 +406,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
                 a.params[(size_t)b * P + kNumBeta + 11] = 0.0f;  // translation z := 0 (head_mesh.py:41)
         }
     };
-    load_raw(0);
+    load_raw(0);  // with the stagers' requests, ahead of the basis: needed after seven groups
     float4 bq[KG];  // the wave's basis slice, resident for the launch
-#pragma unroll
-    for (int G = 0; G < 6; ++G) bq[G] = bsrc[(size_t)G * 256];
     // -- epilogue role: the wave finishes images [8 w, 8 w + 8) of every half-block; lane = (image ei, vertex group eu) walks the
     // vertices eu, eu + 8, eu + 16 of the tile. Their weights and landmark slots stay in registers for the launch.
     const int ei = lane & 7, eu = lane >> 3, li = 8 * wave + ei;
@@ -396,12 +415,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     int lh[3], ln[3];
     bool vl[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int j = eu + 8 * k;
-        vl[k] = j < TV && v0 + j < a.n_verts;
-        const float4 t = vl[k] ? a.vtab[v0 + j] : float4{0.f, 0.f, __int_as_float(-1), __int_as_float(-1)};
-        vW[k] = t.x, vw2[k] = t.y, lh[k] = a.n_lmk > 0 ? __float_as_int(t.z) : -1, ln[k] = __float_as_int(t.w);
-    }
+    for (int k = 0; k < 3; ++k) vl[k] = eu + 8 * k < TV && v0 + eu + 8 * k < a.n_verts;
     float4 k0, k1, k2, k3, k4, k5;  // the constants of this lane's image for the half-block about to be finished
     auto load_consts = [&](int hb) {
         const float4* c = reinterpret_cast<const float4*>(cst + (((hb >> 2) & 1) * kRound + (hb & 3) * HB + li) * CS);
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const bool live = b < B && vl[k];
-            live3[k] = live && a.verts3d != nullptr, livep[k] = live && a.proj != nullptr, livel[k] = live && lh[k] >= 0;
+            live3[k] = live && a.verts3d != nullptr, livep[k] = live && a.proj != nullptr, livel[k] = live && nl > 0 && lh[k] >= 0;
         }
     };
     auto epi_fetch = [&](int k) {
@@ -457,13 +471,27 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     };
     const int n_rounds = (B + kRound - 1) / kRound;
 
-    phase_barrier();  // the arrival words are zero
-    // The rest of the basis slice, ALL of it in flight now: the stagers requested the first A image before they arrived at the
-    // barrier above, and a CU's vector loads return in order -- so the A image is not behind these 80 KB (requested up front,
-    // before the barrier, they put the first MFMA at 6.3 k cycles instead of 4.5 k), while the basis stream no longer waits for
-    // the GEMM to ask for it six groups at a time (first half-block 12.2 k cycles at that pace).
+    stamp(6);
+    phase_barrier();  // the stagers' requests for the first A image are in the load queue (and the arrival words are zero)
+    stamp(7);
+    // The basis slice, ALL of it in flight from here: the CU's vector memory requests are served in order, so the A image -- asked
+    // for in front of the barrier -- is not behind these 104 KB (asked for together with it, they put the first MFMA at 6.3 k
+    // cycles instead of 4.5 k), while the basis stream neither waits for the GEMM to ask for it a few groups at a time (first
+    // half-block 12.2 k cycles at that pace) nor for anybody's data: no wave waits for a load in front of the barrier above.
+    // (in THIS order -- the requests come back in order and group 0 is what the first MFMA waits for; left alone, the scheduler
+    // issued group 0 twenty-fifth)
 #pragma unroll
-    for (int G = 6; G < KG; ++G) bq[G] = bsrc[(size_t)G * 256];
+    for (int G = 0; G < KG; ++G) {
+        bq[G] = bsrc[(size_t)G * 256];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the lanes' rows of the vertex table: weights and landmark slots, first used by the first epilogue -- behind the basis
+    // (unconditional, from a clamped row: a branch around a load makes the wave wait for it on the spot; vl[k] gates every use)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 t = a.vtab[min(v0 + eu + 8 * k, a.n_verts - 1)];
+        vW[k] = t.x, vw2[k] = t.y, lh[k] = __float_as_int(t.z), ln[k] = __float_as_int(t.w);
+    }
     {   // the first half-block: A arrives in parts, the basis slice is still streaming into the registers. The constants of the
         // first 128 images are computed between two of its groups: their ~250 instructions fill time the GEMM would spend waiting
         // for the basis anyway, and nothing in front of the first MFMA waits for the params' tails.

@@ -3,7 +3,7 @@
 
     python tools/trace_pipe.py [batch]
 
-Per wave: 0 start | 1 first seven MFMA groups done (mma) / first loads issued (stager) | 4 constants round 0 written | 3 last barrier
+Per wave: 0 start | 6, 7 at / past the first barrier (stagers: 7 = first part of A(0) published) | 1 first seven MFMA groups done (mma) / first loads issued (stager) | 4 constants round 0 written | 3 last barrier
 passed | 5 end | 12, 13 wall clock (100 MHz); first four half-blocks h: 16+4h before the GEMM / phase start, 17+4h accumulators
 parked / A(h+1) written, 18+4h past the barrier / next loads issued, 19+4h (stagers) past the barrier."""
 import os
@@ -40,6 +40,7 @@ print(f"batch {batch}: wave lifetime {np.median(wall[:, :4]):.2f} us (mma) {np.m
 def med(w, slot):
     return float(np.median(rel[:, w, slot]))
 print("mma waves (cycles since wave start, median over tiles; wave 0 / wave 3):")
+print(f"  at the first barrier {med(0, 6):.0f} / {med(3, 6):.0f}, past it {med(0, 7):.0f} / {med(3, 7):.0f}, basis requests issued {med(0, 16):.0f} / {med(3, 16):.0f}")
 print(f"  first MFMA groups done {med(0, 1):.0f} / {med(3, 1):.0f}; constants round 0 written {med(0, 4):.0f} / {med(3, 4):.0f}; end {med(0, 5):.0f} / {med(3, 5):.0f}")
 for h in range(min(4, (batch + 31) // 32)):
     a = [med(0, 16 + 4 * h + k) for k in range(4)]
@@ -48,7 +49,7 @@ for h in range(min(4, (batch + 31) // 32)):
           f"past barrier {a[2]:.0f}/{b[2]:.0f} (wait {a[2] - a[1]:.0f})")
 print(f"  last half-block finished by all eight waves: {med(0, 5) - med(0, 3):.0f} cycles")
 print("stager waves (wave 4 / wave 7):")
-print(f"  first loads issued {med(4, 1):.0f}; A(0) published {med(4, 2):.0f}; end {med(4, 5):.0f}")
+print(f"  first loads issued {med(4, 1):.0f} / {med(7, 1):.0f}; past the first barrier {med(4, 6):.0f}; first part of A(0) published {med(4, 7):.0f}; A(0) published {med(4, 2):.0f}; end {med(4, 5):.0f}")
 for h in range(min(4, (batch + 31) // 32)):
     a = [med(4, 16 + 4 * h + k) for k in range(4)]
     print(f"  phase {h}: start {a[0]:.0f}  A({h + 1}) written {a[1]:.0f}  loads issued {a[2]:.0f}  past barrier {a[3]:.0f}")
