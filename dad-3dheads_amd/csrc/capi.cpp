@@ -86,7 +86,8 @@ static int decode_kernel_choice() {
     static const int choice = [] {
         const char* e = getenv("DAD3D_DECODE_KERNEL");
         if (!e) return 0;
-        return (e[0] == 'v' && e[1] == '1') ? DAD3D_KERNEL_TWO_ROLE : DAD3D_KERNEL_AUTO;  // "pipe" = the default
+        if (e[0] == 'v' && e[1] == '1') return DAD3D_KERNEL_TWO_ROLE;
+        return std::strcmp(e, "force_pipe") == 0 ? DAD3D_KERNEL_PIPELINED : DAD3D_KERNEL_AUTO;  // "pipe" = the default
     }();
     return choice;
 }
@@ -458,10 +459,11 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     }
     // The pipelined single-role kernel (flame_decode_pipe.hip) takes the inference launches of a covered model (jaw-only, the
     // dad_3dnet.yaml params layout, no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3, outputs below 2 GB); the two-role kernel of
-    // rounds 1-3 keeps the rest, the training forward, and the two batch ranges where it measured ahead (profiles/r04_ab_decode.txt:
-    // 6.7 against 7.8 us for a single image -- its quarter-size instantiation --, 11.6 against 12.1 us at 33 images; 8.0 / 8.6 /
-    // 12.3 / 12.9 / 16.8 / 37.7 / 139 / 272 us against 8.4 / 11.4 / 12.2 / 12.8 / 22.3 / 42.4 / 158 / 324 at 16 / 32 / 48 / 64 /
-    // 96 / 256 / 1024 / 2048).
+    // rounds 1-3 keeps the rest, the training forward, and the two batch ranges where it measured ahead (both kernels forced, one
+    // call, profiles/r04_ab_decode.txt: 6.8 / 6.9 against 7.4 / 7.45 us at 1 / 2 images -- its quarter-size instantiation --, a tie at 4,
+    // 7.7-8.2 against 7.5 from 6 to 12; 11.63 / 11.70 / 11.95 against 11.90 / 11.96 / 12.01 at 33 / 36 / 40, 12.07 against 12.03 at 44).
+    // Elsewhere: 7.7 / 8.4 / 12.15 / 12.7 / 16.8 / 37.6 / 137.6 / 268.5 us against 8.4 / 11.4 / 12.2 / 12.8 / 22.3 / 42.5 / 158 / 324 at
+    // 16 / 32 / 48 / 64 / 96 / 256 / 1024 / 2048.
     const int choice = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
@@ -469,7 +471,7 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         set_error("dad3d_flame_decode: the pipelined kernel does not cover this launch (model, flags or output size)");
         return DAD3D_E_UNSUPPORTED;
     }
-    const bool two_role_ahead = batch <= 8 || (batch > kPipeHalf && batch < 48);
+    const bool two_role_ahead = batch <= 3 || (batch > kPipeHalf && batch <= 40);
     if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE && (choice == DAD3D_KERNEL_PIPELINED || !two_role_ahead)) {
         PipeArgs pa{};
         pa.params = params;
