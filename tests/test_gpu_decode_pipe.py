@@ -139,3 +139,51 @@ def test_duplicate_landmark_indices_the_565_list_and_a_forked_handle(flame_model
     out_twin = twin.decode(p.clone())
     assert out_twin["lmk_xy"].shape == (70, len(idx), 2) and torch.equal(out_twin["lmk_xy"], out["lmk_xy"])
     assert torch.equal(out_twin["verts3d"], out["verts3d"])
+
+
+def test_reference_edge_cases_in_every_half_block_position(meshes, decode_golden):
+    """The reference-generated edge rows (tests/golden/make_decode_golden.py: zero jaw, zero expression, scale clamp, degenerate
+    6-DoF vectors, 4x coefficients) through the FORCED pipelined kernel, tiled over a batch that puts every one of them into the
+    first, a middle and the ragged last half-block and into two constants rounds."""
+    pipe, _ = meshes
+    g = decode_golden
+    edge = g["edge_params"]
+    reps = 27  # 162 rows: five full half-blocks and one of two rows
+    params = np.tile(edge, (reps, 1))
+    dev = torch.from_numpy(params.copy()).cuda()
+    out = pipe.decode(dev, to_2d=False, landmarks=False)
+    torch.cuda.synchronize()
+    sub = g["edge_subset"]
+    v = out["verts3d"].cpu().numpy().reshape(reps, edge.shape[0], -1, 3)
+    p = out["proj"].cpu().numpy().reshape(reps, edge.shape[0], -1, 3)
+    assert np.abs(v[:, :, sub] - g["edge_v3d_sub"][None]).max() < 4 * TOL_V
+    err = np.abs(p[:, :, sub] - g["edge_proj3_sub"][None])
+    assert err[:, :5].max() < TOL_PX and err[:, 5].max() < 4 * TOL_PX
+    assert np.array_equal(v, np.broadcast_to(v[:1], v.shape)) and np.array_equal(p, np.broadcast_to(p[:1], p.shape))  # same bits everywhere
+    assert np.array_equal(dev.cpu().numpy(), np.tile(g["edge_params_after"], (reps, 1)))
+    assert np.all(v[:, 3] == 0) and np.all(v[:, 4] == 0)  # degenerate 6-DoF -> R = 0 (F.normalize's eps)
+
+
+@pytest.mark.parametrize("profile", ["crop", "survey"])
+def test_full_range_jaw_rotations_and_both_camera_profiles(meshes, flame_consts, profile):
+    """The CNN head emits 3 tanh(.) for the jaw's axis-angle too (flame_regression.py:96-104): rotations of up to 5.2 rad, far
+    outside the 0.3 rad the synthetic workload uses -- the kernel's own sine / cosine (flame_math.hpp) must hold the bar there --
+    plus axis-angle vectors that are exactly zero or denormal-small (smplx's `+ 1e-8` inside the norm) and the SURVEY 8d camera
+    (scale + 1 in 0.7..1.3) beside the crop-filling one."""
+    pipe, two = meshes
+    rng = np.random.default_rng(991)
+    params = synthetic.synthetic_params(96, seed=7300, profile=profile)
+    params[:, 400:403] = rng.uniform(-3.0, 3.0, (96, 3)).astype(np.float32)
+    params[0, 400:403] = 0.0
+    params[1, 400:403] = [1e-9, -2e-9, 5e-10]
+    params[2, 400:403] = [3.0, 3.0, 3.0]
+    params[3, 400:403] = [np.pi, 0.0, 0.0]
+    params[4, 400:403] = [0.0, -2.0 * np.pi, 0.0]
+    p = torch.from_numpy(params.copy())
+    v_ref = flame_ref.vertices_3d(flame_consts, p).numpy()
+    p2_ref = flame_ref.reprojected_vertices(flame_consts, p, to_2d=True).numpy()
+    for hm in (pipe, two):
+        out = hm.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True)
+        torch.cuda.synchronize()
+        assert np.abs(out["verts3d"].cpu().numpy() - v_ref).max() < TOL_V
+        assert np.abs(out["proj"].cpu().numpy() - p2_ref).max() < TOL_PX
