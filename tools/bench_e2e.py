@@ -43,6 +43,12 @@ def main():
         out[name] = {"images_per_s_end_to_end": batch / t_all, "ms_per_batch_end_to_end": t_all * 1e3,
                      "ms_cnn_only": t_cnn * 1e3, "ms_decode_only": t_dec * 1e3,
                      "decode_share_of_batch_time": t_dec / t_all}
+    # the whole batch replayed from ONE hipGraph (the CNN's ~200 kernels + the glue + the decode's neighbours; bf16)
+    pred = FaceMeshPredictor.random_init(dtype=torch.bfloat16, tune=True, graph=True, cuda_id=0, flame_model=model,
+                                         landmarks=landmarks.canonical("445", st))
+    t_graph = timed(lambda: pred.predict_tensor(images), 20, 5)
+    out["bf16"]["images_per_s_end_to_end_hipgraph"] = batch / t_graph
+    out["bf16"]["ms_per_batch_end_to_end_hipgraph"] = t_graph * 1e3
     # single image, the reference's call pattern: ~200 launch-bound kernels at batch 1 -> replay them from a hipGraph
     import numpy as np
 
