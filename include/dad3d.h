@@ -180,7 +180,8 @@ dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
  * (csrc/flame_decode_pipe.hip) whenever it covers the launch -- jaw-only model with the dad_3dnet.yaml params layout, inference outputs,
  * no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3 -- and the two-role kernel (csrc/flame_decode.hip) otherwise; DAD3D_KERNEL_TWO_ROLE
  * forces the latter; DAD3D_KERNEL_PIPELINED returns DAD3D_E_UNSUPPORTED from a decode the pipelined kernel does not cover instead of
- * falling back. The environment variable DAD3D_DECODE_KERNEL=v1|pipe sets the process-wide default (A/B timing). */
+ * falling back. The environment variable DAD3D_DECODE_KERNEL=v1|force_pipe sets the process-wide default for handles that have not chosen
+ * (A/B timing; anything else = automatic). */
 #define DAD3D_KERNEL_AUTO 0
 #define DAD3D_KERNEL_TWO_ROLE 1
 #define DAD3D_KERNEL_PIPELINED 2
