@@ -299,14 +299,14 @@ def observed_shader_clock_mhz(lib, handle, call, dev):
     from dad_3dheads_amd import _lib
 
     try:
-        n_rows = 4096 * 32  # >= (workgroups x 8 waves) x 32 stamps of either decode kernel
+        n_rows = int(lib.dad3d_flame_debug_trace_entries(handle, BATCH))  # what either decode kernel stamps for this batch
         trace = torch.zeros(n_rows, dtype=torch.int64, device=dev)
         for _ in range(50):  # clocks as in the timed region
             lib.dad3d_flame_decode(*call)
-        _lib.check(lib.dad3d_flame_debug_trace(handle, trace.data_ptr()))
+        _lib.check(lib.dad3d_flame_debug_trace(handle, trace.data_ptr(), n_rows))
         _lib.check(lib.dad3d_flame_decode(*call))
         torch.cuda.synchronize(dev)
-        _lib.check(lib.dad3d_flame_debug_trace(handle, None))
+        _lib.check(lib.dad3d_flame_debug_trace(handle, None, 0))
         t = trace.cpu().numpy().astype(np.float64)[: 240 * 8 * 32].reshape(240, 8, 32)[:, 0]  # first mma wave of every workgroup
         cyc, wall = t[:, 5] - t[:, 0], (t[:, 13] - t[:, 12]) / 100.0  # cycles, microseconds
         ok = (cyc > 0) & (wall > 0)

@@ -85,7 +85,8 @@ SIGNATURES = {
     "dad3d_flame_profile_end": (_I, [_P, _P, C.POINTER(C.c_double), C.POINTER(_I)]),
     "dad3d_flame_select_kernel": (_I, [_P, _I]),
     "dad3d_flame_handoff_timeouts": (_I, [_P, C.POINTER(C.c_uint)]),
-    "dad3d_flame_debug_trace": (_I, [_P, _P]),
+    "dad3d_flame_debug_trace": (_I, [_P, _P, C.c_uint64]),
+    "dad3d_flame_debug_trace_entries": (C.c_uint64, [_P, _I]),
     "dad3d_mesh_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
     "dad3d_mesh_destroy": (None, [_P]),
     "dad3d_mesh_get_normal": (_I, [_P, _P, _P, _I, _U, _P]),

@@ -77,6 +77,7 @@ struct dad3d_flame {
     int cap_nbb = 0;
     bool profiling = false;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
+    uint64_t trace_capacity = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
 };
@@ -437,6 +438,13 @@ dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n
     return upload_vtab(h, head2);
 }
 
+// entries of a dad3d_flame_debug_trace buffer one launch stamps (the two kernels lay it out differently, include/dad3d.h)
+static uint64_t trace_entries_two_role(const dad3d_flame* h, int batch) {
+    const uint64_t nbb = (batch + kBlockImages - 1) / kBlockImages, pose_blocks = ((uint64_t)(batch + 3) / 4 + 7) / 8 * 8;
+    return ((uint64_t)h->n_tiles_pad8 * nbb * 8 + pose_blocks * 4) * 32;
+}
+static uint64_t trace_entries_pipe(const dad3d_flame* h) { return (uint64_t)h->c->n_tiles_pipe * 8 * 32; }
+
 static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                 float* lmk_xy, int32_t* lmk_px, float* posed, void* stream) {
     DAD3D_REQUIRE(h, "dad3d_flame_decode: null handle");
@@ -457,13 +465,13 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         dad3d_status st = grad_inputs_prepare(h, batch, s);
         if (st) return st;
     }
-    // The pipelined single-role kernel (flame_decode_pipe.hip) takes the inference launches of a covered model (jaw-only, the
+    // The pipelined single-role kernel (flame_decode_pipe.hip) takes EVERY inference launch it covers (jaw-only model, the
     // dad_3dnet.yaml params layout, no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3, outputs below 2 GB); the two-role kernel of
-    // rounds 1-3 keeps the rest, the training forward, and the two batch ranges where it measured ahead (both kernels forced, one
-    // call, profiles/r04_ab_decode.txt: 6.8 / 6.9 against 7.4 / 7.45 us at 1 / 2 images -- its quarter-size instantiation --, a tie at 4,
-    // 7.7-8.2 against 7.5 from 6 to 12; 11.63 / 11.70 / 11.95 against 11.90 / 11.96 / 12.01 at 33 / 36 / 40, 12.07 against 12.03 at 44).
-    // Elsewhere: 7.7 / 8.4 / 12.15 / 12.7 / 16.8 / 37.6 / 137.6 / 268.5 us against 8.4 / 11.4 / 12.2 / 12.8 / 22.3 / 42.5 / 158 / 324 at
-    // 16 / 32 / 48 / 64 / 96 / 256 / 1024 / 2048.
+    // rounds 1-3 keeps the rest and the training forward. Round 4 also sent 1..3 and 33..40 images to the two-role kernel for
+    // 0.3-0.6 us measured on one box (profiles/r04_ab_decode.txt: 6.8 against 7.4 us at B = 1, 11.63 against 11.90 at 33); that
+    // crossover table is gone -- inside box-to-box spread at 33..40, irrelevant next to a 4 ms network at B = 1, and it made the
+    // jaw sine/cosine (flame_math.hpp against OCML) depend on the batch size. DAD3D_DECODE_KERNEL=v1 / dad3d_flame_select_kernel
+    // remain the escape hatch.
     const int choice = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
@@ -471,8 +479,10 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         set_error("dad3d_flame_decode: the pipelined kernel does not cover this launch (model, flags or output size)");
         return DAD3D_E_UNSUPPORTED;
     }
-    const bool two_role_ahead = batch <= 3 || (batch > kPipeHalf && batch <= 40);
-    if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE && (choice == DAD3D_KERNEL_PIPELINED || !two_role_ahead)) {
+    if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE) {
+        DAD3D_REQUIRE(!h->d_trace || h->trace_capacity >= trace_entries_pipe(h), "dad3d_flame_decode: the trace buffer holds %llu entries, "
+                      "this launch stamps %llu (dad3d_flame_debug_trace_entries)", (unsigned long long)h->trace_capacity,
+                      (unsigned long long)trace_entries_pipe(h));
         PipeArgs pa{};
         pa.params = params;
         pa.bpack = h->c->d_bpack_pipe;
@@ -496,6 +506,9 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         if (h->profiling) ++h->prof_launches;
         return DAD3D_OK;
     }
+    DAD3D_REQUIRE(!h->d_trace || h->trace_capacity >= trace_entries_two_role(h, batch), "dad3d_flame_decode: the trace buffer holds %llu "
+                  "entries, this launch stamps %llu (dad3d_flame_debug_trace_entries)", (unsigned long long)h->trace_capacity,
+                  (unsigned long long)trace_entries_two_role(h, batch));
     const int nbb = (batch + kBlockImages - 1) / kBlockImages;
     if (nbb > h->cap_nbb) {
         DAD3D_HIP_TRY(hipDeviceSynchronize());
@@ -623,9 +636,15 @@ dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count) {
     return DAD3D_OK;
 }
 
-dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer) {
+uint64_t dad3d_flame_debug_trace_entries(const dad3d_flame* h, int batch) {
+    if (!h || batch <= 0) return 0;
+    return std::max(trace_entries_two_role(h, batch), trace_entries_pipe(h));
+}
+
+dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer, uint64_t capacity) {
     DAD3D_REQUIRE(h, "null handle");
     h->d_trace = device_buffer;
+    h->trace_capacity = device_buffer ? capacity : 0;
     return DAD3D_OK;
 }
 

@@ -79,7 +79,10 @@ __device__ __forceinline__ void rodrigues_minus_identity_lean(const float r[3], 
     const float angle = n2 * inv;
     const float x = r[0] * inv, y = r[1] * inv, z = r[2] * inv;
     float s, c;
-    sincos_lean(angle, &s, &c);
+    // the three-piece reduction is exact only while k * 1.5703125 is (|x| < ~1e4); a garbage / early-training jaw vector beyond that
+    // takes OCML's huge-argument path like the two-role kernel does (rare branch, skipped by the whole wave otherwise)
+    if (__builtin_expect(angle > 8192.0f, 0)) sincosf(angle, &s, &c);
+    else sincos_lean(angle, &s, &c);
     const float c1 = 1.0f - c;
     const float aa = x * x + y * y + z * z;
     const float cxy = c1 * (x * y), cxz = c1 * (x * z), cyz = c1 * (y * z);

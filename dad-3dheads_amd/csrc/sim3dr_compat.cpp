@@ -4,8 +4,6 @@
 // instead of rasterize_kernel.cpp without a source change -- see INTEGRATION.md.
 #include "../../include/dad3d.h"
 
-#define DAD3D_EXPORT __attribute__((visibility("default")))
-
 DAD3D_EXPORT void _get_tri_normal(float* tri_normal, float* vertices, int* triangles, int ntri, bool norm_flg) {
     dad3d_sim3dr_get_tri_normal(tri_normal, vertices, triangles, ntri, norm_flg ? 1 : 0);
 }

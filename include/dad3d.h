@@ -15,6 +15,12 @@
 
 #include <stdint.h>
 
+/* libdad3d_hip.so is built with -fvisibility=hidden: the functions declared here and the five C++-linkage Sim3DR doubles of
+ * csrc/sim3dr_compat.cpp are its ENTIRE dynamic symbol table (tests/test_capi_symbols.py holds `nm -D` to that). */
+#ifndef DAD3D_EXPORT
+#define DAD3D_EXPORT __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -29,11 +35,11 @@ typedef enum dad3d_status {
     DAD3D_E_NOMEM = 4
 } dad3d_status;
 
-const char* dad3d_last_error(void);
-void dad3d_clear_error(void); /* reset the thread-local message to "" */
-int dad3d_version(void);
+DAD3D_EXPORT const char* dad3d_last_error(void);
+DAD3D_EXPORT void dad3d_clear_error(void); /* reset the thread-local message to "" */
+DAD3D_EXPORT int dad3d_version(void);
 /* Number of visible HIP devices (0 when there is none). Host-only, launches nothing. */
-int dad3d_device_count(void);
+DAD3D_EXPORT int dad3d_device_count(void);
 
 /* ------------------------------------------------------------------------------------------------
  * FLAME / HeadMesh decode
@@ -77,23 +83,23 @@ typedef struct dad3d_flame dad3d_flame; /* opaque: packed basis + scratch reside
 
 /* Upload + repack the model for `device`. Replaces FLAMELayer.__init__ (flame.py:124-180) and
  * HeadMesh.__init__ (head_mesh.py:10-22). `image_size` is HeadMesh._image_size (256). */
-dad3d_status dad3d_flame_create(const dad3d_flame_model* model, const dad3d_flame_consts* consts, float image_size,
+DAD3D_EXPORT dad3d_status dad3d_flame_create(const dad3d_flame_model* model, const dad3d_flame_consts* consts, float image_size,
                                 int device, dad3d_flame** out);
-void dad3d_flame_destroy(dad3d_flame* h);
+DAD3D_EXPORT void dad3d_flame_destroy(dad3d_flame* h);
 /* A second handle on the same device that SHARES the model constants of `parent` (26 MB, reference counted: either may
  * be destroyed first) and owns its hand-off buffers and landmark list (copied from the parent's current one). A handle
  * serves one stream at a time -- its pose-role -> decode-role hand-off block is per handle -- so a serving loop that
  * keeps several batches in flight uses one fork per stream (bench.py does, with two). */
-dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out);
+DAD3D_EXPORT dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out);
 
 /* Number of floats per params row (sum of the consts; 413 for dad_3dnet.yaml). */
-int dad3d_flame_num_params(const dad3d_flame* h);
-int dad3d_flame_num_verts(const dad3d_flame* h);
+DAD3D_EXPORT int dad3d_flame_num_params(const dad3d_flame* h);
+DAD3D_EXPORT int dad3d_flame_num_verts(const dad3d_flame* h);
 
 /* Ordered landmark index list (HOST int64, e.g. the 445 list of model_training/utils.py:62-105 or the
  * per-file lists demo_utils.py:44-46 walks). Duplicates allowed. Replaces np.take(..., indices, axis=0). */
-dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* indices, int n);
-int dad3d_flame_num_landmarks(const dad3d_flame* h);
+DAD3D_EXPORT dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* indices, int n);
+DAD3D_EXPORT int dad3d_flame_num_landmarks(const dad3d_flame* h);
 
 /* One fused decode of B parameter rows. Any output pointer may be NULL (not produced).
  *   params  [B,P] fp32 (read; tz written when DAD3D_MUTATE_PARAMS)
@@ -107,13 +113,13 @@ int dad3d_flame_num_landmarks(const dad3d_flame* h);
  * size; a captured launch keeps its hand-off bookkeeping on the device, so the graph can be replayed any number of
  * times and interleaved with direct calls (about 1.6 us slower per launch than a direct call). The raster and
  * lighting entry points below are capturable as they are (warm up once with the same shapes). */
-dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+DAD3D_EXPORT dad3d_status dad3d_flame_decode(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                 float* lmk_xy, int32_t* lmk_px, void* stream);
 
 /* The same launch for callers that will differentiate: additionally stores posed [B,V,3] = v_posed (template + blend
  * shapes + pose correctives, i.e. smplx lbs before skinning), the operand dad3d_flame_decode_backward needs. No
  * landmark outputs. */
-dad3d_status dad3d_flame_decode_posed(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
+DAD3D_EXPORT dad3d_status dad3d_flame_decode_posed(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                       float* posed, void* stream);
 
 /* Vertex half of the BACKWARD pass of dad3d_flame_decode, for the reference's training callers that differentiate
@@ -129,7 +135,7 @@ dad3d_status dad3d_flame_decode_posed(dad3d_flame* h, float* params, int batch, 
  *   grad_consts  [B,72]  OUT: dL/d(consts), summed over the vertices (deterministic: one workgroup per image)
  * The constants are small differentiable functions of (jaw/neck/eye pose, joints(betas), rot6d, scale, translation);
  * the host mirror (dad_3dheads_amd/autograd.py) takes their derivatives and runs the two library GEMMs. */
-dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned flags, const float* consts, const float* posed,
+DAD3D_EXPORT dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned flags, const float* consts, const float* posed,
                                          const float* grad_verts3d, const float* grad_proj, float* grad_posed,
                                          float* grad_consts, void* stream);
 
@@ -140,7 +146,7 @@ dad3d_status dad3d_flame_decode_backward(dad3d_flame* h, int batch, unsigned fla
  * the batch is at most DAD3D_GRAD_INPUTS_MAX_BATCH -- the range the host mirror uses this entry for (above it a library GEMM
  * is faster) -- and by the first call of this entry otherwise: run one step before capturing a graph. */
 #define DAD3D_GRAD_INPUTS_MAX_BATCH 96
-dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, int batch, float* grad_inputs, void* stream);
+DAD3D_EXPORT dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, int batch, float* grad_inputs, void* stream);
 
 /* Per-image half of the same differentiable decode: everything between a params row and the operands of the per-vertex
  * work (flame.py:191-210 betas / full_pose assembly, smplx batch_rodrigues + batch_rigid_transform + vertices2joints,
@@ -151,31 +157,31 @@ dad3d_status dad3d_flame_grad_inputs(dad3d_flame* h, const float* grad_posed, in
  * ..._backward is its vector-Jacobian product: grad_params [B,P] (every entry written; translation z gets 0) from
  * grad_inputs [B,K] and grad_consts [B,72]. The derivative is taken with dual numbers over the SAME device code that
  * computes the forward values (one lane per input direction), so the two cannot drift apart. */
-int dad3d_flame_num_chain_inputs(const dad3d_flame* h);
-dad3d_status dad3d_flame_pose_chain(dad3d_flame* h, const float* params, int batch, float* inputs, float* consts, void* stream);
-dad3d_status dad3d_flame_pose_chain_backward(dad3d_flame* h, const float* params, int batch, const float* grad_inputs,
+DAD3D_EXPORT int dad3d_flame_num_chain_inputs(const dad3d_flame* h);
+DAD3D_EXPORT dad3d_status dad3d_flame_pose_chain(dad3d_flame* h, const float* params, int batch, float* inputs, float* consts, void* stream);
+DAD3D_EXPORT dad3d_status dad3d_flame_pose_chain_backward(dad3d_flame* h, const float* params, int batch, const float* grad_inputs,
                                              const float* grad_consts, float* grad_params, void* stream);
 
 /* Same, HOST buffers in and out (synchronous; PCIe-inclusive convenience for non-HIP callers). */
-dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
+DAD3D_EXPORT dad3d_status dad3d_flame_decode_host(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d,
                                      float* proj, float* lmk_xy, int32_t* lmk_px);
 
 /* predictor.readjust_3dmm_to_the_input_image (predictor.py:154-176), in place on device params:
  *   s' = (s+1)/scale - 1 ;  t' = (t + 1 - [pad_left,pad_top,0]*2/img_size)/scale - 1
  * `pads_scale` is a DEVICE array [B,3] = (pad_left, pad_top, scale) per row, or NULL with the three
  * scalars applied to every row. */
-dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batch, const float* pads_scale,
+DAD3D_EXPORT dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batch, const float* pads_scale,
                                          float pad_left, float pad_top, float scale, void* stream);
 
 /* Timing aid for bench.py: `_begin` records a hipEvent on `stream`, `_end` records a second one on the same
  * stream, synchronises on it and returns the elapsed milliseconds and the number of decode launches issued
  * through this handle in between. With one fused kernel per decode and launches issued back to back,
  * total_ms / launches is that kernel's average duration including the inter-launch gap. */
-dad3d_status dad3d_flame_profile_begin(dad3d_flame* h, void* stream);
-dad3d_status dad3d_flame_profile_end(dad3d_flame* h, void* stream, double* total_ms, int* launches);
+DAD3D_EXPORT dad3d_status dad3d_flame_profile_begin(dad3d_flame* h, void* stream);
+DAD3D_EXPORT dad3d_status dad3d_flame_profile_end(dad3d_flame* h, void* stream, double* total_ms, int* launches);
 /* How many decode workgroups ever gave up waiting for the pose role's hand-off and recomputed the per-image
  * constants themselves (still correct, slower). Expected 0; synchronises the device. */
-dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
+DAD3D_EXPORT dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
 /* Which kernel a decode launch of this handle takes: DAD3D_KERNEL_AUTO (default) = the pipelined single-role kernel
  * (csrc/flame_decode_pipe.hip) whenever it covers the launch -- jaw-only model with the dad_3dnet.yaml params layout, inference outputs,
  * no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3 -- and the two-role kernel (csrc/flame_decode.hip) otherwise; DAD3D_KERNEL_TWO_ROLE
@@ -185,11 +191,17 @@ dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count);
 #define DAD3D_KERNEL_AUTO 0
 #define DAD3D_KERNEL_TWO_ROLE 1
 #define DAD3D_KERNEL_PIPELINED 2
-dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which);
-/* Diagnostics: DEVICE buffer of [grid blocks][4 waves][32] uint64 that every wave of the fused kernel fills
- * with shader-clock stamps at its phase boundaries (start, loads issued, operands landed, GEMM done, tile
- * staged, end; slots 8.. = one per staging chunk); NULL switches it off. Grid blocks = 8*ceil(ceil(V/21)/8) * ceil(B/64). */
-dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer);
+DAD3D_EXPORT dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which);
+/* Diagnostics: a DEVICE buffer of `capacity` uint64 entries that every wave of the decode kernel fills with shader-clock stamps
+ * (32 entries per wave; slots 12 / 13 = the 100 MHz wall clock at the wave's start / end); NULL switches it off. The two kernels
+ * lay it out differently:
+ *   pipelined   [tiles = ceil(V/20)][8 waves][32]                       slots 0.. = per half-block phase stamps (tools/trace_pipe.py)
+ *   two-role    [8*ceil(ceil(V/21)/8) * ceil(B/64) decode workgroups][8 waves][32], then [4*ceil(B/4) pose waves, padded to 8
+ *               workgroups][32]: 0 start, 1 loads issued, 2 operands landed, 3 GEMM done, 4 tile staged, 5 end (tools/trace_decode.py)
+ * dad3d_flame_debug_trace_entries(h, batch) = the entries a launch of `batch` images can write (the larger of the two layouts);
+ * while a trace buffer is set, a decode whose stamps would not fit its `capacity` returns DAD3D_E_INVALID instead of launching. */
+DAD3D_EXPORT dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_buffer, uint64_t capacity);
+DAD3D_EXPORT uint64_t dad3d_flame_debug_trace_entries(const dad3d_flame* h, int batch);
 
 /* ------------------------------------------------------------------------------------------------
  * Sim3DR: vertex normals + z-buffer rasterisation
@@ -198,28 +210,30 @@ dad3d_status dad3d_flame_debug_trace(dad3d_flame* h, unsigned long long* device_
 typedef struct dad3d_mesh dad3d_mesh; /* opaque: triangle list + vertex->face adjacency in HBM */
 
 /* `triangles` HOST int32 [ntri,3] (numpy intc, as Sim3DR/lib/rasterize.pyx:63-69 requires). */
-dad3d_status dad3d_mesh_create(const int32_t* triangles, int ntri, int nver, int device, dad3d_mesh** out);
-void dad3d_mesh_destroy(dad3d_mesh* m);
+DAD3D_EXPORT dad3d_status dad3d_mesh_create(const int32_t* triangles, int ntri, int nver, int device, dad3d_mesh** out);
+DAD3D_EXPORT void dad3d_mesh_destroy(dad3d_mesh* m);
 
 #define DAD3D_NORMAL_ACCUMULATE 0x1u /* add onto the existing content of `ver_normal` like the C function does;
                                         default = start from zero like Sim3DR/Sim3DR.py:9 */
 /* Batched `_get_normal` (Sim3DR/lib/rasterize_kernel.cpp:158-215; rasterize.h:92).
  *   vertices [B,nver,3] fp32 -> ver_normal [B,nver,3] fp32. Bit-exact with the reference. */
-dad3d_status dad3d_mesh_get_normal(dad3d_mesh* m, float* ver_normal, const float* vertices, int batch,
+DAD3D_EXPORT dad3d_status dad3d_mesh_get_normal(dad3d_mesh* m, float* ver_normal, const float* vertices, int batch,
                                    unsigned flags, void* stream);
 /* Batched `_get_tri_normal` (rasterize_kernel.cpp:87-120): tri_normal [B,ntri,3]. */
-dad3d_status dad3d_mesh_get_tri_normal(dad3d_mesh* m, float* tri_normal, const float* vertices, int batch,
+DAD3D_EXPORT dad3d_status dad3d_mesh_get_tri_normal(dad3d_mesh* m, float* tri_normal, const float* vertices, int batch,
                                        int norm_flg, void* stream);
 /* Batched `_get_ver_normal` (rasterize_kernel.cpp:125-153): tri_normal [B,ntri,3] -> ver_normal [B,nver,3]. */
-dad3d_status dad3d_mesh_get_ver_normal(dad3d_mesh* m, float* ver_normal, const float* tri_normal, int batch,
+DAD3D_EXPORT dad3d_status dad3d_mesh_get_ver_normal(dad3d_mesh* m, float* ver_normal, const float* tri_normal, int batch,
                                        unsigned flags, void* stream);
 
 /* Batched `_rasterize` (rasterize_kernel.cpp:219-292; rasterize.h:98-100).
  *   image    [B,h,w,c] uint8, read-modify-write (background in, render out)
  *   vertices [B,nver,3] fp32 (pixel x, pixel y, depth); colors [B,nver,c] fp32 in [0,1]
  *   depth    [B,h,w] fp32 in/out, or NULL = start from -1e8 (Sim3DR/Sim3DR.py:23) and discard
- *   alpha must be 1 (the only value Python can reach: Sim3DR.py:27-28, rasterize.pyx:95); anything else
- *   returns DAD3D_E_UNSUPPORTED because the reference result is then triangle-order dependent.
+ *   alpha == 1 (the only value Python can reach: Sim3DR.py:27-28, rasterize.pyx:95): the z-buffer kernels below.
+ *   alpha != 1: the reference blends every triangle that improves a pixel's depth, in triangle order (rasterize_kernel.cpp:276-281);
+ *   `raster_blend_kernel` replays exactly that chain per pixel -- bit-exact, for c = 1..4 channels. NaN alpha and c outside 1..4
+ *   return DAD3D_E_INVALID (the reference accepts any c; nothing in it passes another).
  * Bit-exact with the reference for alpha == 1: strict-interior test, `>` depth test, ties to the
  * lowest triangle index, (unsigned char) truncation.
  * Scratch: the handle owns device memory for the per-image triangle records, the 64x64-tile lists and the work queue
@@ -227,12 +241,12 @@ dad3d_status dad3d_mesh_get_ver_normal(dad3d_mesh* m, float* ver_normal, const f
  * synchronises the device). One handle serves one stream at a time; use one handle per concurrent stream.
  * Limits: at most 4096 tiles of 64x64 pixels per image (4096 x 4096, 16384 x 1024, ...), B * tiles < 2^24,
  * ntri < 2^28; beyond them DAD3D_E_INVALID with a message. */
-dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* vertices, const float* colors,
+DAD3D_EXPORT dad3d_status dad3d_mesh_rasterize(dad3d_mesh* m, uint8_t* image, const float* vertices, const float* colors,
                                   float* depth, int batch, int h, int w, int c, float alpha, int reverse,
                                   void* stream);
 /* Batched `_rasterize_triangles` (rasterize_kernel.cpp:295-353): depth [B,h,w] in/out (required),
  * triangle_buffer [B,h,w] int32 and barycentric [B,h,w,3] fp32 written where a triangle wins. */
-dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices, float* depth,
+DAD3D_EXPORT dad3d_status dad3d_mesh_rasterize_triangles(dad3d_mesh* m, const float* vertices, float* depth,
                                             int32_t* triangle_buffer, float* barycentric, int batch, int h, int w,
                                             void* stream);
 
@@ -243,18 +257,18 @@ typedef struct dad3d_light {
     float intensity_ambient, intensity_directional, intensity_specular, specular_exp;
     float color_ambient[3], color_directional[3], light_pos[3], view_pos[3];
 } dad3d_light;
-dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,
+DAD3D_EXPORT dad3d_status dad3d_mesh_phong_light(dad3d_mesh* m, float* light, const float* vertices, const float* normals,
                                     int batch, const dad3d_light* cfg, void* stream);
 /* RenderPipeline's first two steps in ONE launch (lighting.py:64-67: `_get_normal` on a zeroed buffer, then the Phong
  * terms): light [B,nver,3] from the vertices alone; `ver_normal` [B,nver,3] receives the normals, or NULL. */
-dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* ver_normal, const float* vertices,
+DAD3D_EXPORT dad3d_status dad3d_mesh_normal_phong_light(dad3d_mesh* m, float* light, float* ver_normal, const float* vertices,
                                            int batch, const dad3d_light* cfg, void* stream);
 /* Diagnostics: DEVICE buffer of [B * tiles][8 waves][16] uint64 that every wave of the raster kernel fills with
  * 100 MHz wall-clock stamps at its phase boundaries (slots 0-6: start, list sorted, fragments done, after barrier,
  * shaded, after barrier, end; 7: triangles in the tile list; 8-11 / 12-15: wave steps, ticks waiting for records,
  * ticks working, pixel tests of the busiest lane, for the fragment / shading walk); NULL switches it off.
  * tiles = ceil(w/64) * ceil(h/64). */
-dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer);
+DAD3D_EXPORT dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_buffer);
 
 /* `RenderPipeline.__call__` with texture=None (Sim3DR/lighting.py:64-71) for a batch, in TWO launches: the geometry kernel
  * of the raster also computes the vertex normals and the Phong light of its share of the vertices (same arithmetic as
@@ -263,7 +277,7 @@ dad3d_status dad3d_mesh_debug_trace(dad3d_mesh* m, unsigned long long* device_bu
  * Sim3DR.rasterize (1, as before); DAD3D_RENDER_CLEAR = render onto a black background (`bg = np.zeros_like(img)`, the
  * `with_bg_flag=False` call of the reference's demo): the image is zeroed by the geometry launch itself, no fill in front. */
 enum { DAD3D_RENDER_REVERSE = 1, DAD3D_RENDER_CLEAR = 2 };
-dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* vertices, float* light, float* depth, int batch,
+DAD3D_EXPORT dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* vertices, float* light, float* depth, int batch,
                                int h, int w, const dad3d_light* cfg, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -274,7 +288,7 @@ dad3d_status dad3d_mesh_render(dad3d_mesh* m, uint8_t* image, const float* verti
  * Outputs, each optional (NULL): world_homo [B,nver,4] = (MV . [v;1])^T, xy [B,nver,2] = (x/w, H - y/w) - crop,
  * xy_int [B,nver,2] = (int) xy. Agreement with the numpy reference is to fp32 rounding, not bitwise (sgemm order).
  * --------------------------------------------------------------------------------------------- */
-dad3d_status dad3d_project_vertices(const float* vertices, const float* model_view, const float* projection,
+DAD3D_EXPORT dad3d_status dad3d_project_vertices(const float* vertices, const float* model_view, const float* projection,
                                     const float* frame, int batch, int nver, float* world_homo, float* xy,
                                     int32_t* xy_int, int device, void* stream);
 
@@ -294,13 +308,13 @@ dad3d_status dad3d_project_vertices(const float* vertices, const float* model_vi
  *   with point_weight[n] = sum_r w_r * multiplicity_r(n) / N_r and scale = 1 / (B * comps).
  *     loss_terms [B][dad3d_point_loss_terms(n_points)] (the loss is their sum); grad_pred [B,N,comps] or NULL */
 enum { DAD3D_LOSS_L1 = 0, DAD3D_LOSS_L2 = 1, DAD3D_LOSS_SMOOTH_L1 = 2 };
-dad3d_status dad3d_cube_region_loss(const float* pred, const float* target, int batch, int n_verts,
+DAD3D_EXPORT dad3d_status dad3d_cube_region_loss(const float* pred, const float* target, int batch, int n_verts,
                                     const int32_t* region_ptr, const int32_t* region_idx, const float* region_weight,
                                     int n_regions, const int32_t* vert_ptr, const int32_t* vert_region,
                                     const int32_t* vert_pos, int criterion, float* stats, float* loss_terms,
                                     float* grad_pred, int device, void* stream);
-int dad3d_point_loss_terms(int n_points);
-dad3d_status dad3d_weighted_point_loss(const float* pred, const float* target, int batch, int n_points, int comps,
+DAD3D_EXPORT int dad3d_point_loss_terms(int n_points);
+DAD3D_EXPORT dad3d_status dad3d_weighted_point_loss(const float* pred, const float* target, int batch, int n_points, int comps,
                                        const float* point_weight, float scale, int criterion, float* loss_terms,
                                        float* grad_pred, int device, void* stream);
 
@@ -312,7 +326,7 @@ dad3d_status dad3d_weighted_point_loss(const float* pred, const float* target, i
  *                        stride in bytes}; the geometry (py3round, calculate_paddings: predictor.py:117-123) is the caller's
  *   out   [B,3,out_size,out_size] float32
  * mean/std: HOST arrays of 3 floats (the [0,1]-scale constants of A.Normalize). */
-dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_size, const float* mean, const float* std,
+DAD3D_EXPORT dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_size, const float* mean, const float* std,
                                      float* out, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -326,9 +340,9 @@ dad3d_status dad3d_preprocess_images(const int64_t* descs, int batch, int out_si
 #define DAD3D_DTYPE_F32 0
 #define DAD3D_DTYPE_F16 1
 #define DAD3D_DTYPE_BF16 2
-dad3d_status dad3d_nhwc_bias_act(void* y, const void* bias, const void* z /* or NULL */, int64_t n_pixels, int channels, int dtype,
+DAD3D_EXPORT dad3d_status dad3d_nhwc_bias_act(void* y, const void* bias, const void* z /* or NULL */, int64_t n_pixels, int channels, int dtype,
                                  int relu, int device, void* stream);
-dad3d_status dad3d_nhwc_resize_sum(void* out, int n, int oh, int ow, int channels, int dtype, int n_inputs, const void* const* xs,
+DAD3D_EXPORT dad3d_status dad3d_nhwc_resize_sum(void* out, int n, int oh, int ow, int channels, int dtype, int n_inputs, const void* const* xs,
                                    const int* hs, const int* ws, const float* weights, int device, void* stream);
 
 /* Single-image HOST entry points with the argument lists of Sim3DR/lib/rasterize.h:84-100 (`bool` spelled
@@ -338,12 +352,12 @@ dad3d_status dad3d_nhwc_resize_sum(void* out, int n, int oh, int ow, int channel
  * INTEGRATION.md). They stage through the GPU synchronously on device $DAD3D_DEVICE (default 0); the
  * vertex count the reference API omits is derived from the triangle list. The reference signatures
  * return void: failures are reported through dad3d_last_error() and leave the outputs untouched. */
-void dad3d_sim3dr_get_tri_normal(float* tri_normal, float* vertices, int* triangles, int ntri, int norm_flg);
-void dad3d_sim3dr_get_ver_normal(float* ver_normal, float* tri_normal, int* triangles, int nver, int ntri);
-void dad3d_sim3dr_get_normal(float* ver_normal, float* vertices, int* triangles, int nver, int ntri);
-void dad3d_sim3dr_rasterize_triangles(float* vertices, int* triangles, float* depth_buffer, int* triangle_buffer,
+DAD3D_EXPORT void dad3d_sim3dr_get_tri_normal(float* tri_normal, float* vertices, int* triangles, int ntri, int norm_flg);
+DAD3D_EXPORT void dad3d_sim3dr_get_ver_normal(float* ver_normal, float* tri_normal, int* triangles, int nver, int ntri);
+DAD3D_EXPORT void dad3d_sim3dr_get_normal(float* ver_normal, float* vertices, int* triangles, int nver, int ntri);
+DAD3D_EXPORT void dad3d_sim3dr_rasterize_triangles(float* vertices, int* triangles, float* depth_buffer, int* triangle_buffer,
                                       float* barycentric_weight, int ntri, int h, int w);
-void dad3d_sim3dr_rasterize(unsigned char* image, float* vertices, int* triangles, float* colors,
+DAD3D_EXPORT void dad3d_sim3dr_rasterize(unsigned char* image, float* vertices, int* triangles, float* colors,
                             float* depth_buffer, int ntri, int h, int w, int c, float alpha, int reverse);
 
 #ifdef __cplusplus

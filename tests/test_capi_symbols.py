@@ -41,6 +41,17 @@ def test_reference_cpp_prototypes_are_exported():
         assert proto in out, proto
 
 
+def test_nothing_else_is_exported():
+    """The dynamic symbol table is the C ABI and the five Sim3DR doubles, nothing else (-fvisibility=hidden + csrc/exports.map):
+    no launcher, kernel handle, libstdc++ instantiation or __hip_cuid_* leaks out of a drop-in library."""
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    five = {"_Z15_get_tri_normalPfS_Piib", "_Z15_get_ver_normalPfS_Piii", "_Z11_get_normalPfS_Piii",
+            "_Z20_rasterize_trianglesPfPiS_S0_S_iii", "_Z10_rasterizePhPfPiS0_S0_iiiifb"}
+    assert five <= names
+    assert names - five == set(declared_functions()), sorted(names - five - set(declared_functions()))
+
+
 def test_host_only_calls_work_without_gpu():
     lib = _lib.load()
     assert lib.dad3d_version() == 100

@@ -187,3 +187,24 @@ def test_full_range_jaw_rotations_and_both_camera_profiles(meshes, flame_consts,
         torch.cuda.synchronize()
         assert np.abs(out["verts3d"].cpu().numpy() - v_ref).max() < TOL_V
         assert np.abs(out["proj"].cpu().numpy() - p2_ref).max() < TOL_PX
+
+
+def test_huge_jaw_angles_take_the_large_argument_path(meshes, flame_consts):
+    """A garbage / early-training jaw vector (the head's output is unbounded before its tanh saturates in fp32 only by range):
+    beyond ~8e3 rad the kernel's three-piece argument reduction is no longer exact and flame_math.hpp branches to OCML's sincosf,
+    the function the two-role kernel and the oracle use. Angles are powers of two so that the kernel's v_rsq_f32 norm and the
+    oracle's sqrt give the SAME fp32 angle (one ulp of 1e6 rad is 0.06 rad: any other choice tests the norm, not the sine)."""
+    pipe, two = meshes
+    params = synthetic.synthetic_params(40, seed=7700)
+    params[0, 400:403] = [2.0 ** 20, 0.0, 0.0]
+    params[1, 400:403] = [0.0, 2.0 ** 16, 0.0]
+    params[2, 400:403] = [0.0, 0.0, -(2.0 ** 14)]
+    params[35, 400:403] = [-(2.0 ** 22), 0.0, 0.0]  # second half-block
+    p = torch.from_numpy(params.copy())
+    v_ref = flame_ref.vertices_3d(flame_consts, p).numpy()
+    for hm in (pipe, two):
+        out = hm.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True)
+        torch.cuda.synchronize()
+        got = out["verts3d"].cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - v_ref).max() < TOL_V

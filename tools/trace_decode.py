@@ -19,23 +19,25 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dbg = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
 st = synthetic.load_static()
 hm = HeadMesh(flame_model=synthetic.synthetic_flame_model(0, st), landmarks=landmarks.canonical("445", st), static=st, device=0)
+hm.flame.select_kernel("two_role")  # this script parses the two-role kernel's stamp layout (tools/trace_pipe.py: the pipelined one)
 p = torch.from_numpy(synthetic.synthetic_params(batch, seed=0)).cuda()
 nbb = (batch + 63) // 64
 grid = 240 * nbb  # decode-role workgroups (the pose role is not traced)
 n_pose = (batch + 3) // 4
-trace = torch.zeros((grid * 8 + n_pose * 4, 32), dtype=torch.int64, device="cuda")
 lib = _lib.load()
+n_entries = int(lib.dad3d_flame_debug_trace_entries(hm.flame._handle, batch))  # the library's own bound; a launch that would overrun is refused
+trace = torch.zeros((n_entries // 32, 32), dtype=torch.int64, device="cuda")
 for _ in range(20):
     hm.decode(p, to_2d=True, landmarks_px=True)
-_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, trace.data_ptr()))
+_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, trace.data_ptr(), trace.numel()))
 v3 = torch.empty((batch, 5023, 3), device="cuda"); pr = torch.empty((batch, 5023, 2), device="cuda"); lp = torch.empty((batch, 445, 2), dtype=torch.int32, device="cuda")
 drop = os.environ.get("DAD3D_TRACE_DROP", "")  # diagnostics: leave outputs out ("v" = 3d_vertices, "p" = projection, "l" = landmarks)
 _lib.check(lib.dad3d_flame_decode(hm.flame._handle, p.data_ptr(), batch, _lib.TO_2D | dbg, None if "v" in drop else v3.data_ptr(),
                                   None if "p" in drop else pr.data_ptr(), None, None if "l" in drop else lp.data_ptr(), None))
 torch.cuda.synchronize()
-_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None))
+_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None, 0))
 allrows = trace.cpu().numpy().astype(np.float64)
-pose = allrows[grid * 8 :].reshape(n_pose, 4, 32)
+pose = allrows[grid * 8 : grid * 8 + n_pose * 4].reshape(n_pose, 4, 32)
 full = allrows[: grid * 8].reshape(grid, 8, 32)
 t = full[..., :6]
 names = ["issue first loads", "first chunk lands", "GEMM (+staging)", "stage acc tile / hand-off", "epilogue"]

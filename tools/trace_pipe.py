@@ -27,10 +27,11 @@ v3 = torch.empty((batch, 5023, 3), device="cuda"); pr = torch.empty((batch, 5023
 call = (hm.flame._handle, p.data_ptr(), batch, _lib.TO_2D, v3.data_ptr(), pr.data_ptr(), None, lp.data_ptr(), None)
 for _ in range(200):
     lib.dad3d_flame_decode(*call)
-_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, trace.data_ptr()))
+hm.flame.select_kernel("pipelined")  # these stamps are the pipelined kernel's layout
+_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, trace.data_ptr(), trace.numel()))
 _lib.check(lib.dad3d_flame_decode(*call))
 torch.cuda.synchronize()
-_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None))
+_lib.check(lib.dad3d_flame_debug_trace(hm.flame._handle, None, 0))
 t = trace.cpu().numpy().astype(np.float64)[: tiles * 8].reshape(tiles, 8, 32)
 rel = t - t[:, :, 0:1]
 wall = (t[:, :, 13] - t[:, :, 12]) / 100.0
