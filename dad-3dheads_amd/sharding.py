@@ -28,9 +28,12 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None, direct=None) -> torch.Tensor:
-    """All-gather row-sharded `local` ([n_r, ...], n_r = this rank's shard of n_total rows) into the full
-    `[n_total, ...]` tensor on every rank. One collective; works for any dtype the backend supports.
+def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None, direct=None,
+                root: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Gather row-sharded `local` ([n_r, ...], n_r = this rank's shard of n_total rows) into the full `[n_total, ...]`
+    tensor: on every rank (`root=None`, one all-gather) or on group rank `root` only (one gather; the other ranks get
+    None and receive nothing -- SURVEY 8e's "`ncclGather`-style send/recv to rank 0"). One collective; works for any dtype
+    the backend supports.
     `direct`: an `rccl.RcclAllGather` over the same ranks -- the collective is then queued on torch's current stream
     through RCCL's C API instead of the process group's own stream (no event hops; see rccl.py)."""
     if not dist.is_available() or not dist.is_initialized():
@@ -41,18 +44,30 @@ def gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessG
     sizes = shard_sizes(n_total, world)
     if local.shape[0] != sizes[rank]:
         raise ValueError(f"rank {rank} holds {local.shape[0]} rows, its shard of {n_total} is {sizes[rank]}")
+    if root is not None and not (0 <= root < world):
+        raise ValueError(f"root {root} outside world of {world}")
+    receives = root is None or rank == root
     width = max(sizes)
     if width == 0:
-        return local.new_empty((0,) + tuple(local.shape[1:]))
+        return local.new_empty((0,) + tuple(local.shape[1:])) if receives else None
     padded = local
     if local.shape[0] != width:  # ragged: pad to the widest shard for the collective
         padded = local.new_zeros((width,) + tuple(local.shape[1:]))
         padded[: local.shape[0]] = local
-    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
-    if direct is not None:
-        direct.all_gather(out, padded.contiguous())
+    out = local.new_empty((world * width,) + tuple(local.shape[1:])) if receives else None
+    if root is None:
+        if direct is not None:
+            direct.all_gather(out, padded.contiguous())
+        else:
+            dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    elif direct is not None:
+        direct.gather_to_root(out, padded.contiguous(), root=root)
     else:
-        dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+        dst = dist.get_global_rank(group, root) if group is not None else root
+        dist.gather(padded.contiguous(), list(out.view((world, width) + tuple(local.shape[1:])).unbind(0)) if receives else None,
+                    dst=dst, group=group)
+    if not receives:
+        return None
     if all(s == width for s in sizes):
         return out
     return torch.cat([out[r * width : r * width + sizes[r]] for r in range(world)], dim=0)
@@ -98,8 +113,10 @@ class ShardedRenderer:
     geometry kernel (vertex normals + Phong light + triangle records), the tile kernel -- and no host copy."""
 
     def __init__(self, head_mesh, mesh, group: Optional[dist.ProcessGroup] = None, image_size: int = 256,
-                 direct_rccl: bool = False, **light):
-        self.head_mesh, self.mesh, self.group = head_mesh, mesh, group
+                 direct_rccl: bool = False, root: Optional[int] = None, **light):
+        """root: group rank that receives the finished images (the others get None from `__call__`): every rank's 12.6 MB then
+        crosses xGMI once, to one GPU. None = all-gather: every rank ends up with all `world x 12.6 MB`."""
+        self.head_mesh, self.mesh, self.group, self.root = head_mesh, mesh, group, root
         self.direct = None
         if direct_rccl and dist.is_available() and dist.is_initialized():
             from .rccl import RcclAllGather
@@ -120,9 +137,9 @@ class ShardedRenderer:
         verts = self.head_mesh.flame.decode(params_local, proj=True, to_2d=False, flip_z=True, out=self._dec)["proj"]
         return self.mesh.render(verts, self._img, light_out=self._light_buf, clear=True, **self.light)  # black background
 
-    def __call__(self, params_global: torch.Tensor) -> torch.Tensor:
+    def __call__(self, params_global: torch.Tensor) -> Optional[torch.Tensor]:
         """params_global [B,P] (the same tensor on every rank, or at least this rank's rows valid) -> uint8 [B,h,w,3]
-        on every rank."""
+        on every rank (root=None) or on rank `root` alone (None elsewhere)."""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
         n = params_global.shape[0]
@@ -132,4 +149,4 @@ class ShardedRenderer:
         img = self.render_local(mine)
         if not (dist.is_available() and dist.is_initialized()):
             return img.clone()  # render_local's buffer is reused by the next call; the gathered tensor of the other path is fresh
-        return gather_rows(img, n, self.group, self.direct)
+        return gather_rows(img, n, self.group, self.direct, root=self.root)

@@ -39,7 +39,10 @@ def test_vertices_3d_gradient_matches_oracle_autograd(hm, flame_consts, batch, z
     v = hm.vertices_3d(p, zero_rotation=zero_rot)
     assert v.requires_grad and v.device == p.device and v.shape == (batch, 5023, 3)
     with torch.no_grad():
-        assert torch.equal(v, hm.vertices_3d(p.detach(), zero_rotation=zero_rot))  # same launch as the inference path
+        # zero_rotation: both take the two-role kernel (the same launch, bit for bit); otherwise the inference call takes the
+        # pipelined kernel at every batch size (round 5: no crossover table) and the two agree to fp32 rounding
+        infer = hm.vertices_3d(p.detach(), zero_rotation=zero_rot)
+        assert torch.equal(v, infer) if zero_rot else float((v - infer).abs().max()) < 1e-6
     (v * w.cuda()).sum().backward()
     assert close(p.grad, p_ref.grad)
     assert float(p.grad[:, 409:412].abs().max()) == 0.0 and float(p.grad[:, 412].abs().max()) == 0.0  # t, s unused here

@@ -66,6 +66,17 @@ def test_direct_rccl_all_gather_on_the_launch_stream(nccl_world1, head_mesh):
         assert torch.equal(rg.all_gather(torch.empty_like(x), x), x)
     with pytest.raises(ValueError):
         rg.all_gather(torch.empty(5, device="cuda"), torch.empty(6, device="cuda"))
+    # gather-to-root (configs[4]'s default collective): in a world of one the root's own rows, a device copy on the given stream
+    img = (torch.arange(4 * 16 * 16 * 3, device="cuda") % 251).to(torch.uint8).reshape(4, 16, 16, 3)
+    with torch.cuda.stream(side):
+        dst = torch.zeros_like(img)
+        assert rg.gather_to_root(dst, img, root=0, stream=side.cuda_stream) is dst
+    side.synchronize()
+    assert torch.equal(dst, img)
+    with pytest.raises(ValueError):
+        rg.gather_to_root(None, img, root=0)
+    with pytest.raises(ValueError):
+        rg.gather_to_root(dst, img, root=1)
     a = sharding.ShardedLandmarkDecoder(head_mesh)(params)
     b = sharding.ShardedLandmarkDecoder(head_mesh, direct_rccl=True)(params)
     torch.cuda.synchronize()
@@ -121,6 +132,10 @@ def test_sharded_renderer_under_rccl_matches_oracle(nccl_world1, head_mesh, flam
         assert_render_bytes_explained(imgs[i].cpu().numpy(), ref, sim3dr_oracle, v_gpu, faces, ref_light)
     again = renderer(params.cuda())  # buffers are reused: same bytes
     assert torch.equal(again, imgs)
+    for direct in (False, True):  # the images end up on rank 0 only: torch.distributed.gather / grouped ncclSend + ncclRecv
+        at_root = sharding.ShardedRenderer(head_mesh, mesh, root=0, direct_rccl=direct)(params.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(at_root, imgs)
 
 
 def test_kernel_attributes_follow_the_device_not_the_process(static, flame_model):
@@ -160,7 +175,7 @@ def test_bench_plain_and_torchrun_lines_agree_and_two_gpus_are_refused():
     """The driver's contract: `python bench.py --gpus 1` and the same under torch.distributed.run (N = 1: RCCL process group,
     warm-up gather, timed all_gather_into_tensor) print one JSON line each that agree within noise; a 20-step run agrees
     with a 2000-step run within 5 %; `--gpus 2` on this 1-GPU box says what is wrong."""
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"]
     plain = _run_bench(base + ["--gpus", "1", "--steps", "2000", "--warmup", "100"])
     assert plain.returncode == 0, plain.stderr[-800:]
     a = json.loads(plain.stdout.strip().splitlines()[-1])
@@ -184,6 +199,17 @@ def test_bench_plain_and_torchrun_lines_agree_and_two_gpus_are_refused():
     assert "nccl" in b["config"]["parallelism"] and "no process group" in a["config"]["parallelism"]
     assert abs(a["value"] - b["value"]) / a["value"] < 0.10, (a["value"], b["value"])
     assert abs(a["value"] - s["value"]) / a["value"] < 0.05, (a["value"], s["value"])
+    # the device-side aligned start (a 4-byte ncclAllGather in front of the opening event) costs the region nothing: the driver's
+    # own 20-step command under torchrun against the plain 20-step line, compute time to compute time
+    tr20 = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--gpus", "1",
+                       "--steps", "20", "--warmup", "5"])
+    assert tr20.returncode == 0, tr20.stderr[-800:]
+    c = json.loads([ln for ln in tr20.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert "ncclAllGather" in c["config"]["start_alignment"] and c["config"]["start_skew_us"]["max"] >= c["config"]["start_skew_us"]["min"] >= 0
+    assert a["config"]["start_alignment"] == "none" and a["config"]["start_skew_us"] is None
+    print("ms_per_step_compute plain-20 / torchrun-20:", s["ms_per_step_compute"], c["ms_per_step_compute"], "skew", c["config"]["start_skew_us"])
+    assert abs(c["ms_per_step_compute"] - s["ms_per_step_compute"]) / s["ms_per_step_compute"] < 0.05
     if torch.cuda.device_count() < 2:
         two = _run_bench(base + ["--gpus", "2", "--steps", "5", "--warmup", "1"], timeout=120)
         assert two.returncode != 0 and "2 GPUs requested, 1 visible" in two.stderr, two.stderr[-500:]
@@ -193,10 +219,10 @@ def test_bench_eight_ranks_code_path_on_one_gpu():
     """The N = 8 code path of bench.py before an 8-GPU node ever sees it: eight ranks under torch.distributed.run sharing the one
     GPU (DAD3D_BENCH_SHARE_GPU=1: gloo, host-staged gathers), both workloads -- per-rank seeds, MAX over ranks, the gather of
     8 x 64 rows and its check, the two per-step times, clean teardown. Not a multi-GPU measurement, and the line says so."""
-    for workload, steps in (("decode", "100"), ("render", "20")):
+    for workload, steps, extra in (("decode", "100", []), ("render", "20", []), ("render", "20", ["--gather", "all"])):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--gpus", "8", "--steps", steps,
-               "--warmup", "10", "--workload", workload]
+               "--warmup", "10", "--workload", workload] + extra
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
         env["DAD3D_BENCH_SHARE_GPU"] = "1"
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -205,6 +231,11 @@ def test_bench_eight_ranks_code_path_on_one_gpu():
         assert len(lines) == 1  # rank 0 prints ONE JSON line
         d = json.loads(lines[0])
         assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak" and d["value"] > 0
+        # the aligned start runs (through the hook's host-staged collective here) and the skew it absorbed is printed, MAX and MIN over ranks
+        assert "TEST HOOK" in d["config"]["start_alignment"] and d["config"]["start_skew_us"]["max"] >= d["config"]["start_skew_us"]["min"] >= 0
+        print(workload, extra, "start_skew_us", d["config"]["start_skew_us"])
+        if workload == "render":
+            assert d["config"]["gather_mode"] == ("all" if extra else "root")
         if workload == "decode":
             assert d["config"]["outputs_verified"] is True and "not a multi-GPU measurement" in d["config"]["parallelism"]
             assert d["ms_per_step_compute"] > 0 and d["ms_per_step_with_gather"] >= d["ms_per_step_compute"]
@@ -237,3 +268,29 @@ def test_bench_two_ranks_code_path_on_one_gpu():
         else:
             assert d["config"]["gather_verified"] is True and d["config"]["images_with_coverage"] == 1.0
         assert d["value"] > 0
+
+
+def test_driver_command_carries_the_secondary_legs():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (what the driver runs): the contract fields as before, plus -- measured in the
+    same process after the contract region -- long_region, secondary.decode_b256 (BASELINE configs[2], every row held to
+    reference-HeadMesh goldens), secondary.render_b64 (configs[4] per-GPU share, timed images re-rasterised by the reference's own
+    C++) and cpu_baseline_render; the whole run inside the driver's budget."""
+    import time
+
+    t0 = time.time()
+    p = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"])
+    took = time.time() - t0
+    assert p.returncode == 0, p.stderr[-800:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["steps"] == 20 and d["config"]["outputs_verified"] is True and d["roofline"]["frac"] > 0.3 and d["cpu_baseline"]["value"] > 0
+    lr, b256, rnd = d["long_region"], d["secondary"]["decode_b256"], d["secondary"]["render_b64"]
+    assert lr["steps"] == 2000 and abs(lr["ms_per_step"] - d["ms_per_step"]) / d["ms_per_step"] < 0.10
+    assert b256["outputs_verified"] is True and b256["verification"]["rows"] == 256 and 0.4 < b256["frac"] < 1.0 and b256["hbm_frac"] < 1.0
+    assert rnd["timed_images_match_reference_raster"] is True and rnd["images_with_coverage"] == 1.0 and rnd["images_per_sec"] > 1e5
+    assert d["cpu_baseline_render"]["value"] > 0 and d["cpu_baseline_render"]["cores"] == 1
+    assert d["secondary"]["outputs_verified"] is True
+    print(f"driver command took {took:.0f} s; long {lr['ms_per_step'] * 1e3:.2f} us, b256 {b256['ms_per_step'] * 1e3:.2f} us frac {b256['frac']:.3f}, "
+          f"render {rnd['us_per_batch']:.1f} us")
+    assert took < 150  # the driver's run was 32 s in round 4; the secondary legs add ~20 s (two CPU baselines dominate)

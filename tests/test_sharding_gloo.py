@@ -92,6 +92,11 @@ def _image_worker(rank, world, port, n_list, out_dir):
                       torch.arange(8)[None, :, None, None] * 3 + torch.arange(6)[None, None, :, None]) % 251).to(torch.uint8)
             full = sharding.gather_rows(local.contiguous(), n)
             np.save(os.path.join(out_dir, f"img_r{rank}_n{n}.npy"), full.numpy())
+            for root in (0, 1):  # gather-to-root: only `root` receives, the other rank gets None
+                at_root = sharding.gather_rows(local.contiguous(), n, root=root)
+                assert (at_root is None) == (rank != root)
+                if at_root is not None:
+                    np.save(os.path.join(out_dir, f"img_root{root}_n{n}.npy"), at_root.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -107,6 +112,8 @@ def test_gather_rows_uint8_images_two_ranks(tmp_path):
         for r in range(world):
             got = np.load(tmp_path / f"img_r{r}_n{n}.npy")
             assert got.dtype == np.uint8 and np.array_equal(got, ref), (n, r)
+            at_root = np.load(tmp_path / f"img_root{r}_n{n}.npy")  # the default of the render workload (bench.py --gather root)
+            assert at_root.dtype == np.uint8 and np.array_equal(at_root, ref), (n, r)
 
 
 def _pattern_rows(lo, hi):
@@ -130,6 +137,8 @@ def _world8_worker(rank, world, port, n_list, out_dir):
             ref_img = ((torch.arange(0, n)[:, None, None, None] * 5 + torch.arange(4)[None, :, None, None] * 3 +
                         torch.arange(4)[None, None, :, None] + torch.arange(3)[None, None, None, :] * 2) % 251).to(torch.uint8)
             ok = ok and full_img.dtype == torch.uint8 and bool(torch.equal(full_img, ref_img))
+            at_root = sharding.gather_rows(img.contiguous(), n, root=0)  # configs[4]'s default: the images end up on rank 0 only
+            ok = ok and ((at_root is None) if rank != 0 else bool(torch.equal(at_root, ref_img)))
             with open(os.path.join(out_dir, f"w8_r{rank}_n{n}.txt"), "w") as f:
                 f.write("ok" if ok else "MISMATCH")
         dist.barrier()
