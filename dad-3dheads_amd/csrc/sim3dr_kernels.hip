@@ -870,6 +870,16 @@ __device__ __forceinline__ unsigned depth_order_number(float z) {
 // MODE 0: _rasterize (strictly-interior test, colour output)   MODE 1: _rasterize_triangles
 // launch bounds: 4 waves per SIMD = two workgroups per CU (<= 128 VGPRs), so one item's latency-bound phases (sort,
 // resolve) overlap the other's ALU-bound fragment walk
+// A kernel argument read again from the kernarg segment where it is used (one s_load through the scalar cache) instead of being
+// held in scalar registers -- or spilled to a VGPR lane -- for the whole launch. `RasterArgs` is the kernel's only parameter, so its
+// members sit at their struct offsets.
+template <class T>
+__device__ __forceinline__ T kernarg_reload(unsigned byte_offset) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const volatile __attribute__((address_space(4))) T*>(base + byte_offset);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void raster_kernel(RasterArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[kTile * kTile];
@@ -882,9 +892,12 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     __shared__ uint2 s_qe;
     __shared__ int step_ctr;                      // next 64-lane step of the walk to hand to a wave
     unsigned* kw = reinterpret_cast<unsigned*>(keys);  // kw[2p] = ~triangle (low word), kw[2p+1] = depth
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid0 = threadIdx.x;
     const int ntiles = a.sc.tiles_x * a.sc.tiles_y;
     const size_t nt = a.m.ntri;
+    // image dimensions enter 64-bit address arithmetic as UNSIGNED values (zero extension is free; a sign extension of h, w, c and
+    // nver is a scalar register each, held for the whole launch)
+
     const unsigned n_items = a.sc.qhdr[0];
 
     // A workgroup's first item is its own index (no counter: 512 same-address atomics at the start of the launch cost
@@ -895,6 +908,16 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     qe = make_uint2((unsigned)__builtin_amdgcn_readfirstlane((int)qe.x), (unsigned)__builtin_amdgcn_readfirstlane((int)qe.y));
     for (;;) {
     if (item >= n_items) break;
+    // the thread index as a value the optimiser cannot prove loop-invariant: every lane mask derived from it (tid < 192, pj >= o,
+    // cc < pc, lane == 0 ...: ~25 of them, two scalar registers each) would otherwise be hoisted out of the ITEM loop and held
+    // for the whole launch -- that was most of the 61 spilled scalar registers; a mask costs one v_cmp to recompute
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    // (the same for the image size: products like h * w or w * 4 are recomputed per item instead of being kept, or spilled)
+    unsigned h_u = (unsigned)a.h, w_u = (unsigned)a.w, nv_u = (unsigned)a.m.nver;
+    asm volatile("" : "+s"(h_u), "+s"(w_u), "+s"(nv_u));
+    const size_t H = h_u, W = w_u, NV = nv_u;
     const int level = (qe.x >> 24) & 3, part = qe.x >> 26, n_total = (int)qe.y;
     // (integer division runs on the vector unit even for uniform operands: back to scalar registers by hand)
     const size_t b = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((qe.x & 0xFFFFFFu) / ntiles));
@@ -906,9 +929,9 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     const int tw = min(edge, a.w - tx0), th = min(edge, a.h - ty0);
     const int tx1 = tx0 + tw - 1, ty1 = ty0 + th - 1;
     const float3u* rec_b = a.sc.rec + b * nt;
-    const float* vb = a.vertices + b * a.m.nver * 3;
-    const unsigned* glist = a.sc.lists + (b * ntiles + tile) * nt;
-    float* depth_b = a.depth ? a.depth + b * a.h * a.w : nullptr;
+    const float* vb = a.vertices + b * NV * 3;
+    const unsigned* glist = a.sc.lists + (b * (unsigned)ntiles + (unsigned)tile) * nt;
+    float* depth_b = a.depth ? a.depth + b * H * W : nullptr;
     auto stamp = [&](int slot) {
         if (DAD3D_RASTER_TRACE && a.trace && lane == 0) a.trace[((size_t)item * kRasterWaves + (tid >> 6)) * 16 + slot] = wall_clock64();
     };
@@ -925,7 +948,7 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     for (int p = tid; p < edge * th; p += kRasterThreads) {
         const int ly = p >> edge_shift, lx = p & (edge - 1);
         if (lx >= tw) continue;
-        const float z0 = depth_b ? depth_b[(size_t)(ty0 + ly) * a.w + tx0 + lx] : -1e8f;  // Sim3DR.py:23
+        const float z0 = depth_b ? depth_b[(size_t)(unsigned)(ty0 + ly) * W + (unsigned)(tx0 + lx)] : -1e8f;  // Sim3DR.py:23
         keys[ly * kTile + lx] = ((unsigned long long)depth_order(z0) << 32) | kNoTri;
     }
 
@@ -938,6 +961,9 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
         return (x1 < x0 || y1 < y0) ? 0 : (x1 - x0 + 1) * (y1 - y0 + 1);
     };
     auto sort_round = [&](int r) {
+        int tid = tid0;  // opaque per round: the prefix masks die with the round instead of living through the walk
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
         const int n = min(kListCap, n_total - r * kListCap);
         for (int i = tid; i < kClasses * kSpread; i += kRasterThreads) (&ccount[0][0])[i] = 0;
         __syncthreads();
@@ -1151,7 +1177,7 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     auto fetch_next_entry = [&]() {
         if (tid == 0 && !have_next) {
             const unsigned nxt = gridDim.x + claimed;
-            if (nxt < n_items) next_qe = a.sc.queue[nxt];
+            if (nxt < n_items) next_qe = kernarg_reload<const uint2*>(offsetof(RasterArgs, sc) + offsetof(RasterScratch, queue))[nxt];
             have_next = true;
         }
     };
@@ -1165,13 +1191,19 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     // the dead depth half of the key and (D) merges four pixels at a time into the image as whole dwords (byte stores
     // are read-modify-writes in L2). The cost is the same for an item with 100 triangles and one with 4000.
     // C = compile-time channel count of the packed path (3: RGB, 4: RGBA), 0 = any count, bytewise.
-    const float* cb_ = (MODE == 0) ? a.colors + b * a.m.nver * a.c : nullptr;
+    // the channel count as a per-item value: `c == 3`, `c == 4`, `c > 0` and nver * c * 4 otherwise become launch-long scalar state
+    // (wave-uniform booleans are kept as 64-bit lane masks: two registers each)
+    int n_chan = a.c;
+    asm volatile("" : "+s"(n_chan));
+    const float* cb_ = (MODE == 0) ? a.colors + b * NV * (unsigned)n_chan : nullptr;
     auto resolve = [&](auto cc) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
         constexpr int C = decltype(cc)::value;
         constexpr bool packed = MODE == 0 && C != 0;
         constexpr int CC = C ? C : 1;
         constexpr int NP = 2;  // pixels per lane in flight
-        const int nc = C ? C : a.c;
+        const int nc = C ? C : n_chan;
         const int npix = edge * th;
         // A lane's pixels are p = tid + k * 512, k < 8, two per iteration. The corner indices of an iteration's winning
         // triangles are requested one iteration ahead, so that an iteration asks for its corners, record AND colours together:
@@ -1258,11 +1290,11 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
             for (int k = 0; k < NP; ++k) {
                 if (!hit[k]) continue;
                 const int gx = tx0 + lx[k], gy = ty0 + ly[k];
-                const size_t pix = (size_t)gy * a.w + gx;
+                const size_t pix = (size_t)(unsigned)gy * W + (unsigned)gx;
                 if (depth_b) depth_b[pix] = z[k];
                 if (MODE == 1) {
-                    a.tri_buf[b * a.h * a.w + pix] = (int)f[k];
-                    float* bw = a.bary + (b * a.h * a.w + pix) * 3;
+                    a.tri_buf[b * H * W + pix] = (int)f[k];
+                    float* bw = a.bary + (b * H * W + pix) * 3;
                     bw[0] = w0[k];
                     bw[1] = v[k];
                     bw[2] = u[k];
@@ -1278,7 +1310,7 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
                     kw[2 * (ly[k] * kTile + lx[k]) + 1] = pk;  // the depth half of the key is dead by now
                 } else {
                     const int row = a.reverse ? (a.h - 1 - gy) : gy;
-                    uint8_t* px = a.image + ((b * a.h + row) * a.w + gx) * nc;
+                    uint8_t* px = a.image + ((b * H + (unsigned)row) * W + (unsigned)gx) * (unsigned)nc;
                     for (int ch = 0; ch < nc; ++ch) {
                         const float cv = w0[k] * cb_[nc * i0[k] + ch] + v[k] * cb_[nc * i1[k] + ch] + u[k] * cb_[nc * i2[k] + ch];
                         px[ch] = (uint8_t)(f2i_x86(0.0f + 255.0f * cv) & 0xff);
@@ -1300,7 +1332,7 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
             const bool hit[4] = {lo[0] != kNoTri, lo[1] != kNoTri, lo[2] != kNoTri, lo[3] != kNoTri};
             if (!(hit[0] || hit[1] || hit[2] || hit[3])) continue;
             const int gy = ty0 + ly, row = a.reverse ? (a.h - 1 - gy) : gy;
-            unsigned* quad = reinterpret_cast<unsigned*>(a.image + ((b * a.h + row) * a.w + tx0 + lx0) * CC);
+            unsigned* quad = reinterpret_cast<unsigned*>(a.image + ((b * H + (unsigned)row) * W + (unsigned)(tx0 + lx0)) * CC);
             unsigned char bytes[4 * CC];
             if (!(hit[0] && hit[1] && hit[2] && hit[3])) {
 #pragma unroll
@@ -1320,10 +1352,12 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
         }
     };
     {
-        const bool can_pack = MODE == 0 && (a.w & 3) == 0 && (reinterpret_cast<uintptr_t>(a.image) & 3) == 0;
+        unsigned image_lo = (unsigned)reinterpret_cast<uintptr_t>(a.image);
+        asm volatile("" : "+s"(image_lo));
+        const bool can_pack = MODE == 0 && ((w_u | image_lo) & 3) == 0;
         if (DAD3D_RK_ABLATE & 2) {
-        } else if (can_pack && a.c == 3) resolve(std::integral_constant<int, 3>{});
-        else if (can_pack && a.c == 4) resolve(std::integral_constant<int, 4>{});
+        } else if (can_pack && n_chan == 3) resolve(std::integral_constant<int, 3>{});
+        else if (can_pack && n_chan == 4) resolve(std::integral_constant<int, 4>{});
         else resolve(std::integral_constant<int, 0>{});
     }
     }  // part inside the image
@@ -1388,7 +1422,9 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
                 state[ly * kTile + lx] = depth_order(z0);  // next admissible triangle: 0
                 const uint8_t* px = img_b + ((size_t)image_row(ty0 + ly) * a.w + tx0 + lx) * nc;
                 unsigned wv = 0;
-                for (int ch = 0; ch < nc; ++ch) wv |= (unsigned)px[ch] << (8 * ch);
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)  // 1..4 channels: a fixed bound and a guard, not a variable trip count (which the
+                    if (ch < nc) wv |= (unsigned)px[ch] << (8 * ch);  // optimiser vectorised into 110 spilled scalar registers)
                 pixw[ly * kTile + lx] = wv;
             }
             for (;;) {
@@ -1438,7 +1474,8 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
                     tri_uv(ts, (float)(tx0 + lx), (float)(ty0 + ly), u, v);
                     const float w0 = 1.0f - u - v;
                     unsigned wv = pixw[slot], out = 0;
-                    for (int ch = 0; ch < nc; ++ch) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) if (ch < nc) {
                         const float cv = w0 * cb[nc * i0 + ch] + v * cb[nc * i1 + ch] + u * cb[nc * i2 + ch];
                         const float old = (float)(int)((wv >> (8 * ch)) & 0xff);
                         out |= (unsigned)(f2i_x86((1.0f - alpha) * old + alpha * 255.0f * cv) & 0xff) << (8 * ch);
@@ -1459,7 +1496,9 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
                 if ((st >> 32) == 0) continue;  // no fragment passed: the pixel and its depth stay untouched
                 const unsigned wv = pixw[slot];
                 uint8_t* px = img_b + ((size_t)image_row(ty0 + ly) * a.w + tx0 + lx) * nc;
-                for (int ch = 0; ch < nc; ++ch) px[ch] = (uint8_t)((wv >> (8 * ch)) & 0xff);
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+                    if (ch < nc) px[ch] = (uint8_t)((wv >> (8 * ch)) & 0xff);
                 if (depth_b) {  // inverse of the orderable mapping (a depth of -0 is stored as +0: equal as floats)
                     const unsigned dk = (unsigned)st;
                     depth_b[(size_t)(ty0 + ly) * a.w + tx0 + lx] = __uint_as_float((dk & 0x80000000u) ? (dk & 0x7fffffffu) : ~dk);

@@ -67,3 +67,56 @@ def lbs_per_vertex(betas, pose, v_template, shapedirs, posedirs, j_regressor, pa
                 acc += weights[i, k] * (Gp[k] @ h)
         out[i] = acc[:3]
     return out, posed_joints
+
+
+def lbs_vertex_subset(betas, pose, v_template, shapedirs, posedirs, j_regressor, parents, weights, vertex_ids):
+    """The same statement for the listed vertices only (the joints still need every vertex: eq. 10, done as one float64
+    product). Used as the float64 ARBITER of integer-pixel disagreements between two float32 evaluations
+    (tests/test_gpu_parity_pixels.py): a few hundred (image, vertex) pairs out of millions."""
+    betas, pose = np.asarray(betas, np.float64), np.asarray(pose, np.float64)
+    v_template, shapedirs = np.asarray(v_template, np.float64), np.asarray(shapedirs, np.float64)
+    posedirs, j_regressor, weights = np.asarray(posedirs, np.float64), np.asarray(j_regressor, np.float64), np.asarray(weights, np.float64)
+    nj = j_regressor.shape[0]
+    rot = [Rotation.from_rotvec(pose[k]).as_matrix() for k in range(nj)]
+    coeff = np.concatenate([(rot[k] - np.eye(3)).reshape(9) for k in range(1, nj)])
+    t_s = v_template + shapedirs @ betas                      # eq. 8/9, every vertex
+    joints = j_regressor @ t_s                                # eq. 10
+    G = [None] * nj
+    for k in range(nj):
+        local = np.eye(4)
+        local[:3, :3] = rot[k]
+        local[:3, 3] = joints[k] - (joints[parents[k]] if parents[k] >= 0 else 0.0)
+        G[k] = local if parents[k] < 0 else G[parents[k]] @ local
+    Gp = []
+    for k in range(nj):
+        rest_inv = np.eye(4)
+        rest_inv[:3, 3] = -joints[k]
+        Gp.append(G[k] @ rest_inv)
+    out = np.empty((len(vertex_ids), 3))
+    for n, i in enumerate(vertex_ids):
+        t_p = t_s[i] + coeff @ posedirs[:, 3 * i:3 * i + 3]
+        h = np.append(t_p, 1.0)
+        out[n] = sum(weights[i, k] * (Gp[k] @ h) for k in range(nj) if weights[i, k] != 0.0)[:3]
+    return out
+
+
+def projected_pixels_subset(params_row, vertex_ids, v_template, shapedirs, posedirs, j_regressor, parents, weights,
+                            image_size: float = 256.0, mesh_offset_z: float = 0.05):
+    """float64 pixel coordinates [n, 3] of the listed vertices of ONE image, from its float32 params row (dad_3dnet.yaml layout:
+    300 shape | 100 expression | 3 jaw | 6 rotation | 3 translation | 1 scale): lbs above, then model_training/model/flame.py:224-228
+    (z += 0.05, 6-DoF rotation: model/utils.py:92-101 with F.normalize's eps 1e-12) and head_mesh.py:39-45 (scale clamp, tz := 0,
+    (v + 1) / 2 * image_size), every operation in float64."""
+    p = np.asarray(params_row, np.float64)
+    pose = np.zeros((5, 3))
+    pose[2] = p[400:403]
+    v = lbs_vertex_subset(p[:400], pose, v_template, shapedirs, posedirs, j_regressor, parents, weights, vertex_ids)
+    v[:, 2] += mesh_offset_z
+    unit = lambda x: x / max(np.linalg.norm(x), 1e-12)  # noqa: E731
+    b1 = unit(p[403:406])
+    b3 = unit(np.cross(b1, p[406:409]))
+    b2 = -np.cross(b1, b3)
+    R = np.stack((b1, b2, b3), axis=-1)
+    v = v @ R.T
+    s = max(p[412] + 1.0, 1e-8)
+    v = v * s + np.array([p[409], p[410], 0.0])
+    return (v + 1.0) / 2.0 * image_size

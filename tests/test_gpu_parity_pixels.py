@@ -1,0 +1,99 @@
+"""GPU: the integer-pixel parity of BASELINE configs[3] (batch 2048) QUANTIFIED, with a float64 arbiter.
+
+The reference truncates float pixel coordinates (`projected_vertices.astype(int)`, demo_utils.py:42-46). Two float32
+evaluations of the same formula -- torch on the CPU (the oracle: the reference's own arithmetic library) and the HIP kernels --
+differ by ~1e-4 px, so a coordinate that sits within that distance of an integer can truncate differently. This test counts
+those pixels for both decode kernels and both camera profiles, over the 445 landmarks and over the whole mesh, asserts that
+every one of them lies within 1e-3 px of an integer and differs by exactly one, and asks oracle/lbs_independent.py (the SMPL
+paper's formulation in float64) which side truncates like the float64 value. The table goes to gpurun_out/r05_parity_pixels.md
+(committed as profiles/r05_parity_pixels.md)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dad_3dheads_amd import landmarks, synthetic
+from dad_3dheads_amd.head_mesh import HeadMesh
+from oracle import flame_ref
+from oracle.lbs_independent import projected_pixels_subset
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BATCH = 2048
+NEAR = 1e-3  # px: a differing pixel's float coordinate must be this close to an integer
+
+
+def _oracle_projection(consts, params):
+    out = []
+    with torch.no_grad():
+        for lo in range(0, params.shape[0], 256):
+            out.append(flame_ref.reprojected_vertices(consts, torch.from_numpy(params[lo:lo + 256].copy()), to_2d=True).numpy())
+    return np.concatenate(out)
+
+
+def _arbitrate(params, args64, where):
+    """float64 coordinates of the (image, vertex, component) triples in `where` ([n, 3] int array)."""
+    val = np.empty(len(where))
+    for b in np.unique(where[:, 0]):
+        rows = np.nonzero(where[:, 0] == b)[0]
+        verts = np.unique(where[rows, 1])
+        px = projected_pixels_subset(params[b], verts, *args64)
+        pos = {v: i for i, v in enumerate(verts)}
+        for r in rows:
+            val[r] = px[pos[where[r, 1]], where[r, 2]]
+    return val
+
+
+def test_integer_pixels_at_batch_2048_both_kernels_both_cameras(flame_model, flame_consts, static):
+    lm = landmarks.canonical("445", static)
+    fc = flame_consts
+    args64 = tuple(np.asarray(a, np.float64) if a.dtype.kind == "f" else a for a in
+                   (fc.v_template.numpy(), fc.shapedirs.numpy(), fc.posedirs.numpy(), fc.j_regressor.numpy(), fc.parents.numpy(),
+                    fc.lbs_weights.numpy()))
+    lines = ["| camera profile | kernel | pixels | differ from torch-CPU | rate | farthest from an integer (px) | HIP == float64 | torch-CPU == float64 |",
+             "|---|---|---|---|---|---|---|---|"]
+    for profile in ("crop", "survey"):
+        params = synthetic.synthetic_params(BATCH, seed=2048 + len(profile), profile=profile)
+        ref = _oracle_projection(fc, params)                      # float32 [B, V, 2], torch CPU
+        ref_px = ref.astype(int)                                  # demo_utils.py:42
+        for kernel in ("pipelined", "two_role"):
+            hm = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
+            hm.flame.select_kernel(kernel)
+            out = hm.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True, landmarks=False, landmarks_px=True)
+            torch.cuda.synchronize()
+            got = out["proj"].cpu().numpy()
+            got_px = got.astype(int)
+            assert np.array_equal(out["lmk_px"].cpu().numpy(), got_px[:, lm])      # the kernel's own int landmarks = trunc + gather
+            assert np.abs(got - ref).max() < 1e-3
+            for what, sel in (("445 landmarks", lm), ("whole mesh", None)):
+                a, r, f = (got_px, ref_px, ref) if sel is None else (got_px[:, sel], ref_px[:, sel], ref[:, sel])
+                where = np.argwhere(a != r)
+                n_px = a.size
+                far = 0.0
+                hip_right = cpu_right = 0
+                if len(where):
+                    fl = f[tuple(where.T)]
+                    far = float(np.abs(fl - np.round(fl)).max())
+                    assert far < NEAR, (profile, kernel, what, far)
+                    assert np.all(np.abs(a[tuple(where.T)] - r[tuple(where.T)]) == 1)
+                    w_mesh = where.copy()
+                    if sel is not None:
+                        w_mesh[:, 1] = sel[where[:, 1]]
+                    truth = _arbitrate(params, args64, w_mesh).astype(int)        # float64 value, truncated like astype(int)
+                    hip_right = int((truth == a[tuple(where.T)]).sum())
+                    cpu_right = int((truth == r[tuple(where.T)]).sum())
+                    assert hip_right + cpu_right == len(where)                    # they differ by one: float64 sides with exactly one
+                rate = len(where) / n_px
+                assert rate < 2e-4, (profile, kernel, what, rate)
+                lines.append(f"| {profile} | {kernel} | {what}: {n_px} | {len(where)} | {rate:.2e} | {far:.2e} | {hip_right} | {cpu_right} |")
+            del hm
+    text = ("# Integer-pixel parity at batch 2048 (BASELINE configs[3]), both kernels, both camera profiles\n\n"
+            "Written by tests/test_gpu_parity_pixels.py on the GPU box. `differ` = pixels where `(int)` of the HIP coordinate is not `(int)` of the\n"
+            "torch-CPU oracle's (the reference's arithmetic, float32); every one of them is asserted to differ by exactly one and to have a float\n"
+            f"coordinate within {NEAR} px of an integer. The last two columns: which side truncates like the float64 evaluation of the same formula\n"
+            "(oracle/lbs_independent.py: the SMPL paper's formulation, per vertex, scipy's exponential map).\n\n" + "\n".join(lines) + "\n")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r05_parity_pixels.md"), "w") as fh:
+        fh.write(text)
+    print(text)

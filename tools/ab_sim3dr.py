@@ -35,7 +35,8 @@ light = mesh.phong_light(verts, normals)
 img = torch.zeros((B, 256, 256, 3), dtype=torch.uint8, device="cuda")
 lbuf = torch.empty_like(verts)
 res = {"normals": t(lambda: mesh.get_normal(verts, out=normals)), "normals+phong": t(lambda: mesh.phong_light(verts, None)),
-       "rasterize": t(lambda: mesh.rasterize(verts, light, img)), "render": t(lambda: mesh.render(verts, img, light_out=lbuf))}
+       "rasterize": t(lambda: mesh.rasterize(verts, light, img)), "render": t(lambda: mesh.render(verts, img, light_out=lbuf)),
+       "rasterize_alpha0.5": t(lambda: mesh.rasterize(verts, light, img, alpha=0.5), iters=50, warm=5)}  # raster_blend_kernel (boundary completeness)
 orc = Sim3DROracle("port")
 v0 = np.ascontiguousarray(verts[0].cpu().numpy())
 ok_n = np.array_equal(orc.get_normal(v0, faces), mesh.get_normal(verts)[0].cpu().numpy())

@@ -2,7 +2,15 @@
 """End-to-end predictor throughput, reported SEPARATELY from the headline metric ("never mixed into the
 metric"): uint8 frames resident in HBM -> normalise -> DAD-3DNet (hand-declared ResNet-50 + BiFPN + heads, random
 weights, PyTorch-ROCm bf16 channels-last) -> re-adjust kernel -> fused decode + 445 landmarks, all on one stream with
-no host copy in between. Prints one JSON object with the split between the CNN and the decode hot path."""
+no host copy in between. Prints one JSON object with the split between the CNN and the decode hot path.
+
+    python tools/bench_e2e.py [batch] [--cpu] [--cpu-images N]
+
+`--cpu`: the north star's literal comparator in the same run -- "the reference CPU predictor's images/sec": the SAME DAD-3DNet
+declaration (fp32, eval, random weights) on the host CPU, one image per call like predictor.py:97-145 (preprocess -> CNN -> `.cpu()`
+-> readjust -> vertices_3d + reprojected_vertices -> 68 landmarks; plus the 445-landmark int gather of demo_utils.py:42-46), through
+the CPU oracle (oracle/preprocess_ref.py, oracle/flame_ref.py), with torch.set_num_threads in {1, 8, all}; >= 30 images each. Reported
+beside the GPU figures with the ratios; never mixed into the headline metric."""
 import json
 import os
 import sys
@@ -26,8 +34,51 @@ def timed(fn, iters, warm):
     return (time.perf_counter() - t0) / iters
 
 
+def cpu_reference_predictor(model, lmk_idx, n_images: int):
+    """The reference predictor's call sequence on the host CPU (predictor.py:97-145), one 256 x 256 image per call."""
+    import numpy as np
+
+    from dad_3dheads_amd.network import DAD3DNet
+    from oracle import flame_ref, preprocess_ref
+
+    net = DAD3DNet(seed=0).eval()  # the declaration the GPU leg runs, fp32 on the CPU (the reference: a TorchScript of the same graph)
+    consts = flame_ref.FlameConstants.from_model(model)
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 255, (256, 256, 3), dtype=np.uint8) for _ in range(8)]
+    ncpu = os.cpu_count() or 1
+
+    def one(img):
+        x = torch.from_numpy(preprocess_ref.transform(img))[None]                       # predictor.py:86-95
+        with torch.no_grad():
+            out = net(x)                                                                 # predictor.py:97-100
+        params = out["OUTPUT_3DMM_PARAMS"].detach().cpu().float()                       # predictor.py:104
+        post = flame_ref.predictor_postprocess(consts, params.clone(), lmk_idx, input_hw=img.shape[:2])  # :125-145 + demo_utils.py:42-46
+        pts = (out["OUTPUT_2D_LANDMARKS"].detach().cpu().numpy() * 256.0).clip(0, 256).astype(int)     # :147-152 (identity frame)
+        return post, pts
+
+    tried = {}
+    for threads in sorted({t for t in (1, 8, ncpu) if t <= ncpu}):
+        torch.set_num_threads(threads)
+        for i in range(3):
+            one(frames[i])
+        t0 = time.perf_counter()
+        for i in range(n_images):
+            one(frames[i % len(frames)])
+        tried[threads] = n_images / (time.perf_counter() - t0)
+    best = max(tried, key=tried.get)
+    return {"images_per_s": tried[best], "threads": best, "images_per_s_by_threads": {str(k): v for k, v in tried.items()},
+            "images_per_setting": n_images, "host_logical_cores": ncpu, "dtype": "f32",
+            "what": "DAD3DNet (network.py declaration, fp32, eval) + oracle preprocess + oracle predictor_postprocess (readjust, 2 FLAME decodes, "
+                    "445 int landmarks) + 68 landmarks, ONE image per call (predictor.py:97-145), torch CPU"}
+
+
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    want_cpu = "--cpu" in sys.argv
+    cpu_images = int(sys.argv[sys.argv.index("--cpu-images") + 1]) if "--cpu-images" in sys.argv else 30
+    if "--cpu-images" in sys.argv:
+        argv = [a for a in argv if a != str(cpu_images)] or argv
+    batch = int(argv[0]) if argv else 64
     st = synthetic.load_static()
     model = synthetic.synthetic_flame_model(0, st)
     out = {"batch": batch, "data": "synthetic uint8 256x256x3, random-init weights"}
@@ -58,6 +109,12 @@ def main():
                                              landmarks=landmarks.canonical("445", st))
         t = timed(lambda: pred(img1), 50, 10)
         out.setdefault("single_image_ms", {})[name] = t * 1e3
+    if want_cpu:
+        cpu = cpu_reference_predictor(model, landmarks.canonical("445", st), cpu_images)
+        out["cpu_reference_predictor"] = cpu
+        out["ratio_gpu_batch_end_to_end_vs_cpu_predictor"] = out["bf16"]["images_per_s_end_to_end"] / cpu["images_per_s"]
+        out["ratio_gpu_single_image_call_vs_cpu_predictor"] = (1e3 / out["single_image_ms"]["hipgraph"]) / cpu["images_per_s"]
+        out["north_star_target_ratio"] = 200
     print(json.dumps(out))
 
 
