@@ -164,14 +164,14 @@ __device__ __forceinline__ Dual operator/(Dual a, Dual b) {
 __device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
 __device__ __forceinline__ float t_sin(float a) { return sinf(a); }
 __device__ __forceinline__ float t_cos(float a) { return cosf(a); }
-__device__ __forceinline__ float t_floor_at(float a, float lo) { return fmaxf(a, lo); }
+__device__ __forceinline__ float t_floor_at(float a, float lo) { return a < lo ? lo : a; }  // torch.clamp(min=): NaN stays NaN
 __device__ __forceinline__ Dual t_sqrt(Dual a) {
     const float r = sqrtf(a.v);
     return {r, a.d / (2.0f * r)};
 }
 __device__ __forceinline__ Dual t_sin(Dual a) { return {sinf(a.v), cosf(a.v) * a.d}; }
 __device__ __forceinline__ Dual t_cos(Dual a) { return {cosf(a.v), -sinf(a.v) * a.d}; }
-__device__ __forceinline__ Dual t_floor_at(Dual a, float lo) { return a.v >= lo ? a : Dual{lo, 0.0f}; }  // clamp(min=)
+__device__ __forceinline__ Dual t_floor_at(Dual a, float lo) { return a.v < lo ? Dual{lo, 0.0f} : a; }  // clamp(min=), NaN stays NaN
 template <typename T>
 __device__ __forceinline__ T t_const(float c);
 template <>

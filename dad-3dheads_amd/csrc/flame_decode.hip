@@ -270,7 +270,7 @@ __device__ __forceinline__ void constants_from_joints(const DecodeArgs& a, const
         out[60 + r * 3 + 1] = b2[r];
         out[60 + r * 3 + 2] = b3[r];
     }
-    out[69] = fmaxf(in.scale + 1.0f, 1e-8f);  // head_mesh.py:39
+    out[69] = (in.scale + 1.0f) < 1e-8f ? 1e-8f : (in.scale + 1.0f);  // head_mesh.py:39 torch.clamp(min=): NaN stays NaN (not fmaxf)
     out[70] = in.tx;
     out[71] = in.ty;  // translation z := 0 (head_mesh.py:41)
     if (JAW_ONLY) {

@@ -383,7 +383,8 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
         float D[9], G[9];
         rodrigues_minus_identity_lean(jaw, D);  // pose feature of the jaw (smplx lbs step 3) = R_jaw - I
         rot6_to_matrix_lean(rot6, G);
-        const float s = fmaxf(raw_scale + 1.0f, 1e-8f);  // head_mesh.py:39
+        const float sp1 = raw_scale + 1.0f;
+        const float s = sp1 < 1e-8f ? 1e-8f : sp1;  // head_mesh.py:39 torch.clamp(min=): a NaN scale stays NaN (fmaxf would return 1e-8)
         if (first && wave == 0 && lane < 32) {
             // rows of the first A image past the betas, k = 400..415: pose feature R_jaw - I, the template's 1, zero padding
             // (later half-blocks: the stagers copy them out of the ring)

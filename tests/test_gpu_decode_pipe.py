@@ -208,3 +208,26 @@ def test_huge_jaw_angles_take_the_large_argument_path(meshes, flame_consts):
         got = out["verts3d"].cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - v_ref).max() < TOL_V
+
+
+@pytest.mark.parametrize("kernel", ["pipelined", "two_role"])
+def test_poisoned_rows_do_not_leak_into_their_neighbours(meshes, kernel):
+    """A serving batch with garbage rows (NaN / +-Inf anywhere in the 413 floats: an upstream network that diverged on one frame)
+    must cost exactly those rows: the GEMM's image rows are independent, the jaw-joint columns and the per-image constants are per
+    row, so every OTHER row decodes to the same bits as in a clean batch -- whichever half-block, constants round or lane the poisoned
+    rows sit in. (The reference gives NaN for those rows too: torch propagates them through einsum and lbs.)"""
+    pipe, two = meshes
+    hm = pipe if kernel == "pipelined" else two
+    clean = synthetic.synthetic_params(200, seed=7800)
+    dirty = clean.copy()
+    bad = {0: (5, np.nan), 31: (401, np.inf), 32: (405, -np.inf), 63: (412, np.nan), 64: (299, np.inf), 130: (409, np.nan), 199: (350, np.nan)}
+    for row, (col, val) in bad.items():
+        dirty[row, col] = val
+    a = hm.decode(torch.from_numpy(clean).cuda(), to_2d=True, landmarks_px=True)
+    b = hm.decode(torch.from_numpy(dirty).cuda(), to_2d=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    good = torch.tensor([r for r in range(200) if r not in bad], device="cuda")
+    for k in ("verts3d", "proj", "lmk_xy", "lmk_px"):
+        assert torch.equal(a[k][good], b[k][good]), k
+    for row in bad:
+        assert not bool(torch.isfinite(b["proj"][row]).all())  # the poisoned row itself is not silently "repaired"

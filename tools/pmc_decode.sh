@@ -11,7 +11,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1)); rm -rf /tmp/pmcd_$i
   timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcd_$i -- \
-      python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>/tmp/pmcd_err_$i
+      python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > /dev/null 2>/tmp/pmcd_err_$i
   f=$(find /tmp/pmcd_$i -name "*counter_collection.csv" | head -1)
   [ -z "$f" ] && { echo "set $i: no output"; tail -3 /tmp/pmcd_err_$i; continue; }
   cp "$f" "$out/set$i.csv"

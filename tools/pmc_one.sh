@@ -4,7 +4,7 @@
 export TMPDIR=/tmp; root="${GRAFT_REPO_ROOT:-/root/repo}"; tag="$1"; set="$2"; cd /tmp
 out="$root/gpurun_out/pmc_one"; mkdir -p "$out"; rm -rf /tmp/pmc1_$tag
 timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc1_$tag -- \
-    python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>/tmp/pmc1_err_$tag
+    python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > /dev/null 2>/tmp/pmc1_err_$tag
 f=$(find /tmp/pmc1_$tag -name "*counter_collection.csv" | head -1)
 [ -z "$f" ] && { echo "pmc $tag: no output"; tail -3 /tmp/pmc1_err_$tag; exit 0; }
 cp "$f" "$out/$tag.csv"

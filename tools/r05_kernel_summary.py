@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-kernel summary of a rocprofv3 --kernel-trace run of the driver's bench command, with the one split --stats cannot make:
+`flame_decode_pipe_kernel<false>` is launched by two legs of that command (secondary.decode_b256: 256 images; secondary.render_b64:
+64 images) -- the same kernel name and grid (252 workgroups), told apart by duration (a B = 256 launch takes ~40 us, a B = 64 one ~13).
+
+    python tools/r05_kernel_summary.py <dir with *_kernel_trace.csv> [bench.json]   -> markdown on stdout"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for key in ("flame_decode_pipe_kernel<true>", "flame_decode_pipe_kernel<false>", "flame_decode_kernel", "raster_kernel<0>", "raster_blend_kernel",
+                "tri_geometry_kernel<true, 2>", "tri_geometry_kernel<true, 0>", "readjust_kernel", "ncclDevKernel", "copyBuffer", "fillBuffer"):
+        if key in name:
+            return key
+    return name.split("(")[0][-60:]
+
+
+def main():
+    files = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *_kernel_trace.csv under " + sys.argv[1])
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        k = short(r["Kernel_Name"])
+        if k == "flame_decode_pipe_kernel<false>":
+            k += " B=256 (secondary.decode_b256)" if d > 25.0 else " B=64 (secondary.render_b64)"
+        dur[k].append(d)
+    print("| kernel | launches | average us | min us | max us |\n|---|---|---|---|---|")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        print(f"| {k} | {len(v)} | {sum(v) / len(v):.3f} | {min(v):.2f} | {max(v):.2f} |")
+    if len(sys.argv) > 2:
+        d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+        b256 = dur.get("flame_decode_pipe_kernel<false> B=256 (secondary.decode_b256)", [])
+        b64 = dur.get("flame_decode_pipe_kernel<true>", [])
+        print()
+        if b64:
+            a = sum(b64) / len(b64)
+            print(f"headline kernel: rocprofv3 average {a:.3f} us over {len(b64)} launches; the same run printed roofline.kernel_us {d['roofline']['kernel_us']:.3f} "
+                  f"({(a / d['roofline']['kernel_us'] - 1) * 100:+.1f} %), long_region {d['long_region']['ms_per_step'] * 1e3:.3f}")
+        if b256:
+            a = sum(b256) / len(b256)
+            p = d["secondary"]["decode_b256"]["ms_per_step"] * 1e3
+            print(f"B = 256 kernel: rocprofv3 average {a:.3f} us over {len(b256)} launches; the same run printed secondary.decode_b256.ms_per_step {p:.3f} us "
+                  f"({(a / p - 1) * 100:+.1f} %)")
+
+
+if __name__ == "__main__":
+    main()
