@@ -142,3 +142,29 @@ def test_lbs_restatement_agrees_with_an_independent_float64_formulation(flame_mo
         assert np.abs(v32[0].numpy() - v64).max() < 1e-6 * scale, np.abs(v32[0].numpy() - v64).max()
         assert np.abs(j32[0].numpy() - j64).max() < 1e-6 * scale
     assert m.v_template.shape == (5023, 3)
+
+
+def test_float64_pixel_arbiter_is_the_independent_formulation_and_agrees_with_the_oracle(flame_consts):
+    """oracle/lbs_independent.lbs_vertex_subset (the float64 arbiter of tests/test_gpu_parity_pixels.py) is the per-vertex
+    formulation restricted to a vertex list -- equal to `lbs_per_vertex` there to float64 rounding -- and
+    `projected_pixels_subset` (lbs + flame.py:224-228 + head_mesh.py:39-45 in float64) agrees with the float32 oracle to a few ulp(256)."""
+    import torch
+
+    from dad_3dheads_amd import synthetic
+    from oracle import flame_ref
+    from oracle.lbs_independent import lbs_per_vertex, lbs_vertex_subset, projected_pixels_subset
+
+    fc = flame_consts
+    args = (fc.v_template.numpy(), fc.shapedirs.numpy(), fc.posedirs.numpy().astype(np.float64), fc.j_regressor.numpy(), fc.parents.numpy(),
+            fc.lbs_weights.numpy())
+    ids = np.array([0, 3, 1777, 3931, 4477, 5022])
+    rng = np.random.default_rng(5)
+    betas = (rng.standard_normal(400) * 0.6).astype(np.float32)
+    pose = (rng.standard_normal((5, 3)) * 0.5).astype(np.float32)
+    full, _ = lbs_per_vertex(betas, pose, *args)
+    assert np.abs(lbs_vertex_subset(betas, pose, *args, ids) - full[ids]).max() < 1e-12
+    for profile in ("crop", "survey"):
+        p = synthetic.synthetic_params(3, seed=31, profile=profile)
+        ref = flame_ref.reprojected_vertices(fc, torch.from_numpy(p.copy()), to_2d=False).numpy()
+        got = projected_pixels_subset(p[1], ids, *args)
+        assert np.abs(got - ref[1, ids]).max() < 2e-4
