@@ -25,7 +25,7 @@ def main():
     if not files:
         raise SystemExit("no *_kernel_trace.csv under " + sys.argv[1])
     dur = defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Start_Timestamp"])):  # launch order
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         k = short(r["Kernel_Name"])
         if k == "flame_decode_pipe_kernel<false>":
@@ -44,10 +44,13 @@ def main():
             print(f"headline kernel: rocprofv3 average {a:.3f} us over {len(b64)} launches; the same run printed roofline.kernel_us {d['roofline']['kernel_us']:.3f} "
                   f"({(a / d['roofline']['kernel_us'] - 1) * 100:+.1f} %), long_region {d['long_region']['ms_per_step'] * 1e3:.3f}")
         if b256:
-            a = sum(b256) / len(b256)
-            p = d["secondary"]["decode_b256"]["ms_per_step"] * 1e3
-            print(f"B = 256 kernel: rocprofv3 average {a:.3f} us over {len(b256)} launches; the same run printed secondary.decode_b256.ms_per_step {p:.3f} us "
-                  f"({(a / p - 1) * 100:+.1f} %)")
+            leg = d["secondary"]["decode_b256"]
+            p, steps = leg["ms_per_step"] * 1e3, int(leg["steps"])
+            a_all, timed = sum(b256) / len(b256), b256[-steps:]  # the leg's LAST pass is the timed one (untimed settle passes precede it)
+            a = sum(timed) / len(timed)
+            print(f"B = 256 kernel: rocprofv3 average over the timed pass (the last {len(timed)} of its {len(b256)} launches; {leg.get('settle_passes')} untimed "
+                  f"settle passes of the same length and 50 warm-up launches precede it, clock still ramping: average over all {a_all:.3f} us) {a:.3f} us; "
+                  f"the same run printed secondary.decode_b256.ms_per_step {p:.3f} us ({(a / p - 1) * 100:+.1f} %)")
 
 
 if __name__ == "__main__":
