@@ -551,6 +551,39 @@ def secondary_render_b64(hm, static, dev, rank_seed: int, steps: int = 200, cpu_
            "images_with_coverage": covered}
     timed = [(np.ascontiguousarray(renderer._dec["proj"][i].cpu().numpy()), np.ascontiguousarray(renderer._light_buf[i].cpu().numpy()),
               img[i].cpu().numpy()) for i in (0, BATCH - 1)]
+    # the serving shape of the same workload: TWO batches of 64 in flight (a forked decode handle, a mesh handle and buffers per stream,
+    # steps alternate) -- one batch's latency-bound phases overlap the other's ALU-bound ones. Kernels of different streams overlap, so this
+    # is the wall clock between synchronizes over `steps` steps (same settle rule); its first image of the second lane is checked as well.
+    stream2 = torch.cuda.Stream(dev)
+    params2 = torch.from_numpy(synthetic.synthetic_params(BATCH, seed=rank_seed + 1)).to(dev)
+    with torch.cuda.stream(stream2):
+        renderer2 = ShardedRenderer(hm.fork(), Mesh(faces, N_VERTS, device=dev.index))
+        renderer2.render_local(params2)
+    torch.cuda.synchronize(dev)
+    lanes = ((renderer, stream, params), (renderer2, stream2, params2))
+
+    def two_stream_pass():
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            r, st, p = lanes[k & 1]
+            with torch.cuda.stream(st):
+                r.render_local(p)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+
+    prev, passes2 = None, 0
+    while passes2 < settle:
+        t2 = two_stream_pass()
+        passes2 += 1
+        if prev is not None and abs(t2 - prev) <= 0.01 * prev:
+            break
+        prev = t2
+    t2 = two_stream_pass()
+    leg["two_streams"] = {"us_per_batch": t2 * 1e6, "images_per_sec": BATCH / t2, "settle_passes": passes2, "steps": steps,
+                          "value_from": "wall clock between synchronizes, two batches of 64 in flight (steps alternate between two streams)"}
+    timed.append((np.ascontiguousarray(renderer2._dec["proj"][0].cpu().numpy()), np.ascontiguousarray(renderer2._light_buf[0].cpu().numpy()),
+                  renderer2._img[0].cpu().numpy()))
     cpu = cpu_baseline_render(timed[0][0], faces, timed, budget_s=cpu_budget_s)
     leg["timed_images_match_reference_raster"] = cpu.pop("timed_images_match")
     leg["speedup_vs_cpu_baseline_render"] = leg["images_per_sec"] / cpu["value"]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel summary of a rocprofv3 --kernel-trace run of the driver's bench command, with the one split --stats cannot make:
 `flame_decode_pipe_kernel<false>` is launched by two legs of that command (secondary.decode_b256: 256 images; secondary.render_b64:
-64 images) -- the same kernel name and grid (252 workgroups), told apart by duration (a B = 256 launch takes ~40 us, a B = 64 one ~13).
+64 images) -- the same kernel name and grid (252 workgroups), told apart by LAUNCH ORDER: the B = 256 leg comes first and issues exactly
+50 warm-up launches + (settle_passes + 1) x steps, both printed in the bench line (durations would not do: in the render leg's two-stream
+part kernels overlap and a 64-image launch can take as long as a 256-image one).
 
     python tools/r05_kernel_summary.py <dir with *_kernel_trace.csv> [bench.json]   -> markdown on stdout"""
 import csv
@@ -24,18 +26,25 @@ def main():
     files = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)
     if not files:
         raise SystemExit("no *_kernel_trace.csv under " + sys.argv[1])
-    dur = defaultdict(list)
+    bench = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]) if len(sys.argv) > 2 else None
+    n_b256 = None
+    if bench and "secondary" in bench:
+        leg = bench["secondary"]["decode_b256"]
+        n_b256 = 50 + (int(leg["settle_passes"]) + 1) * int(leg["steps"])
+    dur, seen_false = defaultdict(list), 0
     for r in sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Start_Timestamp"])):  # launch order
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         k = short(r["Kernel_Name"])
         if k == "flame_decode_pipe_kernel<false>":
-            k += " B=256 (secondary.decode_b256)" if d > 25.0 else " B=64 (secondary.render_b64)"
+            seen_false += 1
+            first_leg = (seen_false <= n_b256) if n_b256 is not None else d > 25.0
+            k += " B=256 (secondary.decode_b256)" if first_leg else " B=64 (secondary.render_b64, one and two streams)"
         dur[k].append(d)
     print("| kernel | launches | average us | min us | max us |\n|---|---|---|---|---|")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         print(f"| {k} | {len(v)} | {sum(v) / len(v):.3f} | {min(v):.2f} | {max(v):.2f} |")
-    if len(sys.argv) > 2:
-        d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    if bench:
+        d = bench
         b256 = dur.get("flame_decode_pipe_kernel<false> B=256 (secondary.decode_b256)", [])
         b64 = dur.get("flame_decode_pipe_kernel<true>", [])
         print()
