@@ -231,3 +231,32 @@ def test_poisoned_rows_do_not_leak_into_their_neighbours(meshes, kernel):
         assert torch.equal(a[k][good], b[k][good]), k
     for row in bad:
         assert not bool(torch.isfinite(b["proj"][row]).all())  # the poisoned row itself is not silently "repaired"
+
+
+@pytest.mark.parametrize("batch", [35600, 36000])
+def test_maximum_sizes_either_side_of_the_2_gb_output_boundary(flame_model, static, flame_consts, batch):
+    """The pipelined kernel addresses its outputs with 32-bit buffer offsets and covers launches whose largest output stays below
+    2 GB (35 628 rows of [5023, 3] floats); one row more and the C ABI hands the launch to the two-role kernel (64-bit addressing).
+    Both sides of that boundary, 4.3 GB per output: every row equals the row it repeats (the batch tiles 64 distinct rows) and the
+    first / last / boundary rows match the oracle -- an offset that wrapped would show as a wrong or untouched row near the end."""
+    lm = landmarks.canonical("445", static)
+    hm = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)  # automatic kernel choice, as a caller gets it
+    base = synthetic.synthetic_params(64, seed=7900)
+    reps = (batch + 63) // 64
+    params = torch.from_numpy(np.tile(base, (reps, 1))[:batch].copy()).cuda()
+    out = hm.decode(params, to_2d=False, landmarks_px=True)
+    torch.cuda.synchronize()
+    ref_v = flame_ref.vertices_3d(flame_consts, torch.from_numpy(base.copy())).numpy()
+    ref_p = flame_ref.reprojected_vertices(flame_consts, torch.from_numpy(base.copy()), to_2d=False).numpy()
+    for row in (0, 31, 32, 63, 64, batch // 2, batch - 65, batch - 33, batch - 2, batch - 1):
+        assert np.abs(out["verts3d"][row].cpu().numpy() - ref_v[row % 64]).max() < TOL_V, row
+        assert np.abs(out["proj"][row].cpu().numpy() - ref_p[row % 64]).max() < TOL_PX, row
+    idx = torch.arange(batch, device="cuda") % 64
+    for k in ("verts3d", "proj", "lmk_px"):
+        first = out[k][:64]
+        for lo in range(0, batch, 4096):  # chunked: no second 4 GB tensor
+            hi = min(batch, lo + 4096)
+            assert torch.equal(out[k][lo:hi], first[idx[lo:hi]]), (k, lo)
+    assert bool((params[:, 411] == 0).all())  # tz := 0 written back for every row
+    del out
+    torch.cuda.empty_cache()
