@@ -181,10 +181,13 @@ class RcclAllGather:
         base = out.data_ptr()
         if self.world > 1:
             _check(self.lib, self.lib.ncclGroupStart(), "ncclGroupStart")
-            for r in range(self.world):
-                if r != root:
-                    _check(self.lib, self.lib.ncclRecv(base + r * nbytes, nbytes, _NCCL_CHAR, r, self.comm, st), "ncclRecv")
-            _check(self.lib, self.lib.ncclGroupEnd(), "ncclGroupEnd")
+            try:
+                for r in range(self.world):
+                    if r != root:
+                        _check(self.lib, self.lib.ncclRecv(base + r * nbytes, nbytes, _NCCL_CHAR, r, self.comm, st), "ncclRecv")
+            finally:  # a group is never left open: a failing ncclRecv must not swallow every later call of this thread into it
+                end_status = self.lib.ncclGroupEnd()
+            _check(self.lib, end_status, "ncclGroupEnd")
         if base + root * nbytes != inp.data_ptr():
             _device_copy(base + root * nbytes, inp.data_ptr(), nbytes, stream)
         return out
