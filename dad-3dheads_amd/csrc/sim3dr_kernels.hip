@@ -1376,6 +1376,15 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
     }
 }
 
+#ifndef DAD3D_BLEND_BIG_CLASS  // class c = box area <= 2^(c+1) pixels inside the tile
+#define DAD3D_BLEND_BIG_CLASS 5
+#endif
+#ifndef DAD3D_BLEND_ABLATE  // diagnostics only (results wrong, timing meaningful): 1 no walk, 2 resolve without its global loads, 4 one pass only
+#define DAD3D_BLEND_ABLATE 0
+#endif
+#ifndef DAD3D_BLEND_COUNT  // diagnostics build: pass / item / list-entry counters into the dad3d_mesh_debug_trace buffer
+#define DAD3D_BLEND_COUNT 0
+#endif
 // _rasterize with alpha != 1 (rasterize_kernel.cpp:268-284). The reference walks the triangles in index order and blends every
 // fragment that passes the running depth test into the pixel: (unsigned char)((1 - alpha) * old + alpha * 255 * colour), then
 // raises the pixel's depth. Per pixel that is a CHAIN: the fragments that are records (strictly deeper than everything before
@@ -1384,7 +1393,7 @@ __global__ __launch_bounds__(kRasterThreads, DAD3D_RASTER_WAVES_PER_SIMD) void r
 // after its last blended triangle (ds_min_u64 on index << 32 | orderable depth); the winners are blended in a resolve step, and
 // the passes stop when no pixel found a successor. A head mesh has two to four layers, so a handful of passes -- this path is
 // unreachable from the reference's Python (Sim3DR.py:27-28 passes alpha = 1) and exists for the boundary's sake; it reuses the
-// geometry kernel's records, tile lists and work queue. One lane per triangle, 1 to 4 channels.
+// geometry kernel's records, tile lists and work queue. Small boxes one lane each, large ones the whole wave (round 5); 1 to 4 channels.
 __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs a, float alpha) {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[kTile * kTile];   // candidate of this pass: tri << 32 | depth
     __shared__ __attribute__((aligned(16))) unsigned long long state[kTile * kTile];  // next admissible triangle << 32 | depth so far
@@ -1414,6 +1423,7 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
         float* depth_b = a.depth ? a.depth + b * a.h * a.w : nullptr;
         uint8_t* img_b = a.image + b * (size_t)a.h * a.w * nc;
         auto image_row = [&](int gy) { return a.reverse ? (a.h - 1 - gy) : gy; };
+        if (DAD3D_BLEND_COUNT && a.trace && tid == 0) atomicAdd(a.trace + 1, 1ull), atomicAdd(a.trace + 2, (unsigned long long)n_total);  // items, list entries
         if (tw > 0 && th > 0) {
             for (int p = tid; p < edge * th; p += kRasterThreads) {
                 const int ly = p / edge, lx = p % edge;
@@ -1430,32 +1440,78 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
             for (;;) {
                 for (int p = tid; p < kTile * th; p += kRasterThreads) keys[p] = ~0ull;
                 if (tid == 0) s_any = 0;
+                if (DAD3D_BLEND_COUNT && a.trace && tid == 0) atomicAdd(a.trace + 0, 1ull);  // diagnostics build: passes
                 __syncthreads();
-                for (int i = tid; i < n_total; i += kRasterThreads) {
-                    const unsigned f = glist[i] & kIdMask;
+                // The walk of one pass. A triangle's box inside the item holds 1 to 4096 pixels and 70 % of a head's pixel tests come from
+                // boxes of more than 32; with one lane per triangle (round 4) a wave took as long as its largest box while most lanes idled.
+                // Now a wave reads 64 list entries at once; a lane walks its OWN triangle when the entry's area class says <= 32 pixels
+                // (class within the tile, an upper bound for a part of it), and the triangles above that are taken one after the other by
+                // the whole wave, 64 box pixels per step. Same per-pixel arithmetic, and ds_min_u64 makes the candidate independent of
+                // who tested which pixel -- identical bits (tests/test_gpu_raster_alpha.py, tests/perf/raster_soak.py).
+                struct Corners {  // what a lane keeps of its triangle: the three corners, inv, the box clipped to the item
+                    float x0, y0, z0, x1, y1, z1, x2, y2, z2, inv;
+                    int bx0, bx1, by0, by1;
+                };
+                auto load_tri = [&](unsigned f, Corners& c) {
                     const float3u rc = rec_b[f];
                     const unsigned bbx = __float_as_uint(rc.y), bby = __float_as_uint(rc.z);
-                    const int x0 = max((int)(bbx & 0xffff), tx0), x1 = min((int)(bbx >> 16), tx1);
-                    const int y0 = max((int)(bby & 0xffff), ty0), y1 = min((int)(bby >> 16), ty1);
-                    if (x1 < x0 || y1 < y0) continue;
+                    c.bx0 = max((int)(bbx & 0xffff), tx0), c.bx1 = min((int)(bbx >> 16), tx1);
+                    c.by0 = max((int)(bby & 0xffff), ty0), c.by1 = min((int)(bby >> 16), ty1);
+                    if (c.bx1 < c.bx0 || c.by1 < c.by0) return false;
                     const int i0 = a.m.tri[3 * (size_t)f], i1 = a.m.tri[3 * (size_t)f + 1], i2 = a.m.tri[3 * (size_t)f + 2];
-                    const TriSetup ts = setup_from_corners(vb[3 * i0], vb[3 * i0 + 1], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i2], vb[3 * i2 + 1], rc.x);
-                    const float z0 = vb[3 * i0 + 2], z1 = vb[3 * i1 + 2], z2 = vb[3 * i2 + 2];
-                    for (int y = y0; y <= y1; ++y)
-                        for (int x = x0; x <= x1; ++x) {
-                            float u, v;
-                            tri_uv(ts, (float)x, (float)y, u, v);
-                            const float w0 = 1.0f - u - v;
-                            if (!(u > 0.0f && v > 0.0f && w0 > 0.0f)) continue;
-                            const float z = w0 * z0 + v * z1 + u * z2;
-                            if (z != z) continue;  // NaN never passes `>`
-                            const int slot = (y - ty0) * kTile + (x - tx0);
-                            const unsigned long long st = state[slot];
-                            const unsigned dk = depth_order_number(z);
-                            if (dk > (unsigned)st && f >= (unsigned)(st >> 32))
-                                (void)__hip_atomic_fetch_min(&keys[slot], ((unsigned long long)f << 32) | dk, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                    c.x0 = vb[3 * i0], c.y0 = vb[3 * i0 + 1], c.z0 = vb[3 * i0 + 2];
+                    c.x1 = vb[3 * i1], c.y1 = vb[3 * i1 + 1], c.z1 = vb[3 * i1 + 2];
+                    c.x2 = vb[3 * i2], c.y2 = vb[3 * i2 + 1], c.z2 = vb[3 * i2 + 2];
+                    c.inv = rc.x;
+                    return true;
+                };
+                auto test_pixel = [&](const TriSetup& ts, float z0, float z1, float z2, unsigned f, int x, int y) {
+                    float u, v;
+                    tri_uv(ts, (float)x, (float)y, u, v);
+                    const float w0 = 1.0f - u - v;
+                    if (!(u > 0.0f && v > 0.0f && w0 > 0.0f)) return;
+                    const float z = w0 * z0 + v * z1 + u * z2;
+                    if (z != z) return;  // NaN never passes `>`
+                    const int slot = (y - ty0) * kTile + (x - tx0);
+                    const unsigned long long st = state[slot];
+                    const unsigned dk = depth_order_number(z);
+                    if (dk > (unsigned)st && f >= (unsigned)(st >> 32))
+                        (void)__hip_atomic_fetch_min(&keys[slot], ((unsigned long long)f << 32) | dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+                constexpr unsigned kBlendBigClass = DAD3D_BLEND_BIG_CLASS;  // area class >= this: the whole wave takes the triangle
+                const int lane = tid & 63;
+                for (int base = (tid >> 6) * 64; base < ((DAD3D_BLEND_ABLATE & 1) ? 0 : n_total); base += kRasterThreads) {
+                    // all 64 triangles of the group are fetched side by side (three dependent round trips, once per group); a large
+                    // triangle's data then reaches the other lanes through v_readlane, not through three more round trips each
+                    const int i = base + lane;
+                    const unsigned e = i < n_total ? glist[i] : ~0u;
+                    const unsigned f_own = e & kIdMask;
+                    Corners c{};
+                    const bool ok = e != ~0u && load_tri(f_own, c);
+                    const bool big = ok && (e >> 28) >= kBlendBigClass;
+                    if (ok && !big) {
+                        const TriSetup ts = setup_from_corners(c.x0, c.y0, c.x1, c.y1, c.x2, c.y2, c.inv);
+                        for (int y = c.by0; y <= c.by1; ++y)
+                            for (int x = c.bx0; x <= c.bx1; ++x) test_pixel(ts, c.z0, c.z1, c.z2, f_own, x, y);
+                    }
+                    unsigned long long todo = __ballot(big);
+                    while (todo) {  // wave-uniform loop: one large triangle at a time, all 64 lanes on its box
+                        const int j = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
+                        auto bi = [&](int v) { return __builtin_amdgcn_readlane(v, j); };
+                        const unsigned f = (unsigned)bi((int)f_own);
+                        const TriSetup ts = setup_from_corners(bf(c.x0), bf(c.y0), bf(c.x1), bf(c.y1), bf(c.x2), bf(c.y2), bf(c.inv));
+                        const float z0 = bf(c.z0), z1 = bf(c.z1), z2 = bf(c.z2);
+                        const int x0 = bi(c.bx0), x1 = bi(c.bx1), y0 = bi(c.by0), y1 = bi(c.by1);
+                        const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
+                        const float rcp_bw = __builtin_amdgcn_rcpf((float)bw);
+                        for (int p = lane; p < area; p += 64) {
+                            // exact p / bw for p < 4096, bw <= 64: (p + 0.5) / bw is at least 1 / 128 away from an integer, the product's error < 1e-3
+                            const int py = (int)(((float)p + 0.5f) * rcp_bw), px = p - py * bw;
+                            test_pixel(ts, z0, z1, z2, f, x0 + px, y0 + py);
                         }
+                    }
                 }
                 __syncthreads();
                 bool any = false;
@@ -1467,16 +1523,17 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
                     if (k == ~0ull) continue;
                     any = true;
                     const unsigned f = (unsigned)(k >> 32);
-                    const int i0 = a.m.tri[3 * (size_t)f], i1 = a.m.tri[3 * (size_t)f + 1], i2 = a.m.tri[3 * (size_t)f + 2];
-                    const TriSetup ts = setup_from_corners(vb[3 * i0], vb[3 * i0 + 1], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i2], vb[3 * i2 + 1],
-                                                           rec_b[f].x);
+                    const bool fake = (DAD3D_BLEND_ABLATE & 2) != 0;
+                    const int i0 = fake ? 1 : a.m.tri[3 * (size_t)f], i1 = fake ? 2 : a.m.tri[3 * (size_t)f + 1], i2 = fake ? 3 : a.m.tri[3 * (size_t)f + 2];
+                    const TriSetup ts = fake ? setup_from_corners(1.f, 2.f, 9.f, 3.f, 4.f, 8.f, 0.02f)
+                                             : setup_from_corners(vb[3 * i0], vb[3 * i0 + 1], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i2], vb[3 * i2 + 1], rec_b[f].x);
                     float u, v;
                     tri_uv(ts, (float)(tx0 + lx), (float)(ty0 + ly), u, v);
                     const float w0 = 1.0f - u - v;
                     unsigned wv = pixw[slot], out = 0;
 #pragma unroll
                     for (int ch = 0; ch < 4; ++ch) if (ch < nc) {
-                        const float cv = w0 * cb[nc * i0 + ch] + v * cb[nc * i1 + ch] + u * cb[nc * i2 + ch];
+                        const float cv = fake ? u : w0 * cb[nc * i0 + ch] + v * cb[nc * i1 + ch] + u * cb[nc * i2 + ch];
                         const float old = (float)(int)((wv >> (8 * ch)) & 0xff);
                         out |= (unsigned)(f2i_x86((1.0f - alpha) * old + alpha * 255.0f * cv) & 0xff) << (8 * ch);
                     }
@@ -1485,7 +1542,7 @@ __global__ __launch_bounds__(kRasterThreads) void raster_blend_kernel(RasterArgs
                 }
                 if (any) s_any = 1;
                 __syncthreads();
-                if (!s_any) break;
+                if (!s_any || (DAD3D_BLEND_ABLATE & 4)) break;
                 __syncthreads();  // everybody has read s_any before the next pass clears it
             }
             for (int p = tid; p < edge * th; p += kRasterThreads) {
