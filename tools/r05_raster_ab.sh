@@ -2,6 +2,8 @@
 # Round 5: raster kernels with / without the scalar-register spills. Same call, same box:
 #   product                = this tree (raster_kernel<0> 0 spills / 100 VGPR, raster_blend_kernel 0 spills)
 #   tools/_variants/lib_r04raster.so = round 4's sim3dr_kernels.hip (61 / 23 / 110 spills) rebuilt by tools/build_variant_sim3dr.sh
+# Build the comparison library first (authoring container):
+#   git show 94943aa:dad-3dheads_amd/csrc/sim3dr_kernels.hip > /tmp/sim_old.hip && tools/build_variant_sim3dr.sh r04raster "" /tmp/sim_old.hip
 # Output: gpurun_out/r05_raster/{ab.txt, pmc_*.txt, stats_*.csv}
 export TMPDIR=/tmp
 root="${GRAFT_REPO_ROOT:-/root/repo}"; out="$root/gpurun_out/r05_raster"; mkdir -p "$out"
