@@ -523,6 +523,25 @@ def secondary_decode_b256(hm, lib, lmk_idx, dev, steps: int = 400, settle: int =
     except Exception as e:
         out["verification"] = {"checked": False, "why": f"{type(e).__name__}: {e}"}
         out["outputs_verified"] = None
+    # BASELINE configs[3]'s per-GPU work (2048 rows over 8 GPUs = 256 each, only the 445 projected landmarks are gathered): the same rows,
+    # landmark outputs only -> the C ABI runs the sub-model of the listed vertices (include/dad3d.h: dad3d_flame_num_landmark_vertices).
+    lmk_only = torch.zeros_like(lmk_px)
+    call_l = (hm.flame._handle, params.data_ptr(), b, _lib.TO_2D | _lib.MUTATE_PARAMS, None, None, None, lmk_only.data_ptr(), stream.cuda_stream)
+
+    def step_l():
+        st = lib.dad3d_flame_decode(*call_l)
+        if st:
+            _lib.check(st)
+
+    tl, passes_l = events_per_step(step_l, steps, stream, dev, warmup=50, settle=settle)
+    diff = lmk_only != lmk_px  # against the whole-mesh launch above (another kernel: equal except on float boundaries)
+    xy = proj3[:, torch.from_numpy(lmk_idx).to(dev), :2]
+    near = (xy - torch.round(xy)).abs() < 1e-3
+    ok_l = bool(near[diff].all()) and int((lmk_only - lmk_px).abs().max()) <= 1 and int(lmk_only.abs().max()) > 0
+    out["landmarks_only"] = {"workload": "BASELINE configs[3] per-GPU share: 256 rows -> 445 int landmarks only (what the final gather moves)",
+                             "sub_model_vertices": int(lib.dad3d_flame_num_landmark_vertices(hm.flame._handle)), "steps": steps,
+                             "settle_passes": passes_l, "ms_per_step": tl * 1e3, "images_per_sec": b / tl,
+                             "landmark_px_differ_from_whole_mesh_launch": int(diff.sum()), "outputs_verified": ok_l}
     return out
 
 
@@ -790,6 +809,7 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         out["secondary"]["render_b64"] = render
         out["cpu_baseline_render"] = cpu_render
         out["secondary"]["outputs_verified"] = bool(out["secondary"]["decode_b256"]["outputs_verified"]) and \
+            bool(out["secondary"]["decode_b256"]["landmarks_only"]["outputs_verified"]) and \
             bool(render["timed_images_match_reference_raster"]) and bool(out["config"]["outputs_verified"])
     return out
 

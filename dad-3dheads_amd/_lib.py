@@ -72,6 +72,7 @@ SIGNATURES = {
     "dad3d_flame_num_verts": (_I, [_P]),
     "dad3d_flame_set_landmarks": (_I, [_P, _P, _I]),
     "dad3d_flame_num_landmarks": (_I, [_P]),
+    "dad3d_flame_num_landmark_vertices": (_I, [_P]),
     "dad3d_flame_decode": (_I, [_P, _P, _I, _U, _P, _P, _P, _P, _P]),
     "dad3d_flame_decode_posed": (_I, [_P, _P, _I, _U, _P, _P, _P, _P]),
     "dad3d_flame_decode_backward": (_I, [_P, _I, _U, _P, _P, _P, _P, _P, _P, _P]),

@@ -80,6 +80,10 @@ struct dad3d_flame {
     uint64_t trace_capacity = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
+    // Landmark-only launches (SURVEY 7.1 "landmark-only fast path"; BASELINE configs[3]'s per-GPU work): a second handle over the
+    // SUB-MODEL of the vertices the landmark list names (445 of 5023: 22 tiles instead of 240), built by dad3d_flame_set_landmarks
+    // from the packed basis; a decode that asks for landmark outputs only runs there. Same per-vertex arithmetic, ~11x less of it.
+    dad3d_flame* lmk_sub = nullptr;
 };
 
 // Process-wide default of dad3d_flame_select_kernel: DAD3D_DECODE_KERNEL=v1 forces the two-role kernel of rounds 1-3 (A/B timing).
@@ -358,6 +362,8 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
 
 void dad3d_flame_destroy(dad3d_flame* h) {
     if (!h) return;
+    if (h->lmk_sub) dad3d_flame_destroy(h->lmk_sub);
+    h->lmk_sub = nullptr;
     DeviceGuard guard(h->device);
     for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials,
                     (void*)h->d_grad_partials, (void*)h->d_vtab})
@@ -373,6 +379,7 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     DeviceGuard guard(parent->device);
     DAD3D_REQUIRE(guard.ok, "cannot select HIP device %d", parent->device);
     std::unique_ptr<dad3d_flame> h(new dad3d_flame(*parent));  // layout, tiling, shared constants
+    h->lmk_sub = nullptr;  // forked below: the sub-model's constants are shared like the model's
     h->d_lmk_head = h->d_lmk_next = nullptr;
     h->d_vtab = nullptr;
     h->d_imgc = nullptr;
@@ -406,6 +413,13 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
             return DAD3D_E_HIP;
         }
     }
+    if (parent->lmk_sub) {
+        dad3d_status st2 = dad3d_flame_fork(parent->lmk_sub, &h->lmk_sub);
+        if (st2) {
+            dad3d_flame_destroy(h.release());
+            return st2;
+        }
+    }
     *out = h.release();
     return DAD3D_OK;
 }
@@ -413,20 +427,22 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
 int dad3d_flame_num_params(const dad3d_flame* h) { return h ? h->lay.n_params : -1; }
 int dad3d_flame_num_verts(const dad3d_flame* h) { return h ? h->n_verts : -1; }
 int dad3d_flame_num_landmarks(const dad3d_flame* h) { return h ? h->n_lmk : -1; }
+int dad3d_flame_num_landmark_vertices(const dad3d_flame* h) { return (h && h->lmk_sub) ? h->lmk_sub->n_verts : 0; }
 
-dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n) {
-    DAD3D_REQUIRE(h && n >= 0 && (idx || n == 0), "dad3d_flame_set_landmarks: bad argument");
-    std::vector<int> head(h->n_verts, -1), next(n, -1);
+// the per-vertex slot chains of a landmark list: head2[v] = {first slot of vertex v, the slot after it}, next[s] = the slot after s
+static void landmark_chains(const int64_t* idx, int n, int n_verts, std::vector<int>& head2, std::vector<int>& next) {
+    std::vector<int> head(n_verts, -1);
+    next.assign(n, -1);
     for (int s = n - 1; s >= 0; --s) {  // reverse walk: each vertex's chain comes out in ascending slot order
-        DAD3D_REQUIRE(idx[s] >= 0 && idx[s] < h->n_verts, "landmark index %lld out of range [0,%d)", (long long)idx[s],
-                      h->n_verts);
         next[s] = head[idx[s]];
         head[idx[s]] = s;
     }
-    std::vector<int> head2((size_t)h->n_verts * 2, -1);  // what the kernel stages per tile: {head, next[head]}
-    for (int v = 0; v < h->n_verts; ++v)
+    head2.assign((size_t)n_verts * 2, -1);  // what the kernel stages per tile: {head, next[head]}
+    for (int v = 0; v < n_verts; ++v)
         if (head[v] >= 0) head2[(size_t)v * 2] = head[v], head2[(size_t)v * 2 + 1] = next[head[v]];
-    DeviceGuard guard(h->device);
+}
+
+static dad3d_status install_landmark_lists(dad3d_flame* h, const std::vector<int>& head2, const std::vector<int>& next, int n) {
     int* d_next = nullptr;
     dad3d_status st = upload(&d_next, next);
     if (st) return st;
@@ -436,6 +452,98 @@ dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n
     h->d_lmk_next = d_next;
     h->n_lmk = n;
     return upload_vtab(h, head2);
+}
+
+static bool landmark_subset_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DAD3D_LANDMARK_SUBSET");  // =0: landmark-only launches decode the whole mesh like any other (A/B timing)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// (Re)build h->lmk_sub for the list just installed: the model restricted to the distinct vertices the list names, in ascending
+// vertex order, with the list remapped onto it. The basis fragments are copied out of the parent's pack (a column's 416 values do not
+// depend on which tile holds it), so the sub-model multiplies the same numbers in the same order: a landmark-only launch returns the
+// bits the two-role kernel returns for those vertices in a full launch. No sub-model when the list names more than a third of the mesh.
+static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, int n) {
+    if (h->lmk_sub) dad3d_flame_destroy(h->lmk_sub);
+    h->lmk_sub = nullptr;
+#if defined(DAD3D_MFMA32) && DAD3D_MFMA32
+    return DAD3D_OK;  // diagnostics build with the 32x32x2 fragment order: not mirrored here
+#endif
+    if (!landmark_subset_enabled() || n <= 0) return DAD3D_OK;
+    std::vector<int> where(h->n_verts, -1), uniq;
+    for (int s = 0; s < n; ++s) where[idx[s]] = 0;
+    for (int v = 0; v < h->n_verts; ++v)
+        if (where[v] == 0) where[v] = (int)uniq.size(), uniq.push_back(v);
+    const int nu = (int)uniq.size();
+    if ((size_t)nu * 3 > (size_t)h->n_verts) return DAD3D_OK;
+    const int KG = h->kgroups, nt_sub = (nu + kTileVerts - 1) / kTileVerts;
+    std::vector<float> full((size_t)h->n_tiles * KG * 4 * 64 * 4), w8((size_t)h->n_verts * 8);
+    std::vector<float> jdirs((size_t)3 * kNumJoints * h->n_betas), j0(3 * kNumJoints);
+    DAD3D_HIP_TRY(hipMemcpy(full.data(), h->c->d_bpack, full.size() * sizeof(float), hipMemcpyDeviceToHost));
+    DAD3D_HIP_TRY(hipMemcpy(w8.data(), h->c->d_w8, w8.size() * sizeof(float), hipMemcpyDeviceToHost));
+    DAD3D_HIP_TRY(hipMemcpy(jdirs.data(), h->c->d_jdirs, jdirs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    DAD3D_HIP_TRY(hipMemcpy(j0.data(), h->c->d_j0, j0.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> sub((size_t)nt_sub * KG * 4 * 64 * 4, 0.0f), w8s((size_t)nu * 8);
+    for (int t = 0; t < nt_sub; ++t)
+        for (int g = 0; g < KG; ++g)
+            for (int w = 0; w < 4; ++w)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int col = w * 16 + (lane & 15), u = t * kTileVerts + col / 3;
+                    if (col >= kTileVerts * 3 || u >= nu) continue;
+                    const int v = uniq[u], scol = (v % kTileVerts) * 3 + col % 3;  // the column's place in the parent's tile
+                    const float* src = &full[((((size_t)(v / kTileVerts) * KG + g) * 4 + scol / 16) * 64 + (scol % 16) + 16 * (lane >> 4)) * 4];
+                    float* dst = &sub[((((size_t)t * KG + g) * 4 + w) * 64 + lane) * 4];
+                    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+                }
+    for (int u = 0; u < nu; ++u) std::copy(&w8[(size_t)uniq[u] * 8], &w8[(size_t)uniq[u] * 8 + 8], &w8s[(size_t)u * 8]);
+    std::vector<int64_t> remapped(n);
+    for (int s = 0; s < n; ++s) remapped[s] = where[idx[s]];
+    std::vector<int> head2, next;
+    landmark_chains(remapped.data(), n, nu, head2, next);
+
+    std::unique_ptr<dad3d_flame> q(new dad3d_flame(*h));  // layout, K depth, image size
+    q->lmk_sub = nullptr;
+    q->d_lmk_head = q->d_lmk_next = nullptr;
+    q->d_vtab = nullptr;
+    q->d_imgc = nullptr;
+    q->d_sync = nullptr;
+    q->d_bwd_partials = q->d_grad_partials = nullptr;
+    q->bwd_cap = 0, q->grad_cap = 0, q->arrive_total = 0, q->cap_nbb = 0;
+    q->profiling = false;
+    q->d_trace = nullptr, q->trace_capacity = 0;
+    q->ev_first = q->ev_last = nullptr;
+    q->prof_launches = 0;
+    q->kernel_choice = DAD3D_KERNEL_TWO_ROLE;  // no pipelined pack for the sub-model: its tiles walk the batch one after the other
+    q->n_verts = nu;
+    q->n_tiles = nt_sub;
+    q->n_tiles_pad8 = (nt_sub + 7) / 8 * 8;
+    q->n_lmk = n;
+    q->c = std::make_shared<FlameConsts>();
+    q->c->device = h->device;
+    dad3d_status st;
+    if ((st = upload(&q->c->d_bpack, sub)) || (st = upload(&q->c->d_jdirs, jdirs)) || (st = upload(&q->c->d_j0, j0)) ||
+        (st = upload(&q->c->d_w8, w8s)) || (st = upload(&q->d_lmk_head, head2)) || (st = upload(&q->d_lmk_next, next)) ||
+        (st = upload(&q->d_sync, std::vector<unsigned>(kSyncWords, 0u))) || (st = flame_reserve(q.get(), 1))) {
+        dad3d_flame_destroy(q.release());
+        return st;
+    }
+    h->lmk_sub = q.release();
+    return DAD3D_OK;
+}
+
+dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n) {
+    DAD3D_REQUIRE(h && n >= 0 && (idx || n == 0), "dad3d_flame_set_landmarks: bad argument");
+    for (int s = 0; s < n; ++s)
+        DAD3D_REQUIRE(idx[s] >= 0 && idx[s] < h->n_verts, "landmark index %lld out of range [0,%d)", (long long)idx[s], h->n_verts);
+    std::vector<int> head2, next;
+    landmark_chains(idx, n, h->n_verts, head2, next);
+    DeviceGuard guard(h->device);
+    dad3d_status st = install_landmark_lists(h, head2, next, n);
+    if (st) return st;
+    return build_landmark_subset(h, idx, n);
 }
 
 // entries of a dad3d_flame_debug_trace buffer one launch stamps (the two kernels lay it out differently, include/dad3d.h)
@@ -457,6 +565,14 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     DAD3D_REQUIRE(!(posed && (flags & DAD3D_COMPAT_CROSS_B3)), "DAD3D_COMPAT_CROSS_B3 is inference-only (dad3d_flame_decode_posed refuses it)");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // Landmark outputs only (BASELINE configs[3]'s per-GPU work; sharding.ShardedLandmarkDecoder): the sub-model of the listed vertices,
+    // 22 column tiles instead of 240, each workgroup one 64-image block -- unless the caller pinned a kernel (A/B timing, diagnostics).
+    if (h->lmk_sub && !verts3d && !proj && !posed && (lmk_xy || lmk_px) &&
+        (h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice()) == DAD3D_KERNEL_AUTO && !(flags & DAD3D_COMPAT_CROSS_B3) && !h->d_trace) {
+        dad3d_status st = decode_impl(h->lmk_sub, params, batch, flags, nullptr, nullptr, lmk_xy, lmk_px, nullptr, stream);
+        if (!st && h->profiling) ++h->prof_launches;
+        return st;
+    }
     // A training forward: what its backward pass needs exists before any of it can be captured into a graph -- for the batches
     // the host mirror sends to dad3d_flame_grad_inputs (up to DAD3D_GRAD_INPUTS_MAX_BATCH; above it takes the library GEMM and
     // the split-K scratch, tens to hundreds of MB, would never be used) and for models the kernel covers (otherwise the

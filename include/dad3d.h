@@ -100,6 +100,13 @@ DAD3D_EXPORT int dad3d_flame_num_verts(const dad3d_flame* h);
  * per-file lists demo_utils.py:44-46 walks). Duplicates allowed. Replaces np.take(..., indices, axis=0). */
 DAD3D_EXPORT dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* indices, int n);
 DAD3D_EXPORT int dad3d_flame_num_landmarks(const dad3d_flame* h);
+/* Landmark-only launches (every vertex output NULL, a landmark output given -- BASELINE configs[3]'s per-GPU work, the landmark-only fast
+ * path of SURVEY 7.1) run on the SUB-MODEL of the distinct vertices the list names, built by dad3d_flame_set_landmarks: 445 of 5023 vertices
+ * = 22 column tiles instead of 240, the same per-vertex arithmetic on the same basis values (bit-identical to what the two-role kernel
+ * returns for those vertices in a full launch). This returns the number of vertices of that sub-model, 0 when there is none (empty list, a
+ * list naming more than a third of the mesh, DAD3D_LANDMARK_SUBSET=0). A handle pinned with dad3d_flame_select_kernel(TWO_ROLE / PIPELINED)
+ * or tracing decodes the whole mesh for such a launch like for any other. */
+DAD3D_EXPORT int dad3d_flame_num_landmark_vertices(const dad3d_flame* h);
 
 /* One fused decode of B parameter rows. Any output pointer may be NULL (not produced).
  *   params  [B,P] fp32 (read; tz written when DAD3D_MUTATE_PARAMS)

@@ -289,6 +289,8 @@ def test_driver_command_carries_the_secondary_legs():
     assert lr["steps"] == 2000 and abs(lr["ms_per_step"] - d["ms_per_step"]) / d["ms_per_step"] < 0.10
     assert b256["outputs_verified"] is True and b256["verification"]["rows"] == 256 and 0.4 < b256["frac"] < 1.0 and b256["hbm_frac"] < 1.0
     assert rnd["timed_images_match_reference_raster"] is True and rnd["images_with_coverage"] == 1.0 and rnd["images_per_sec"] > 1e5
+    lo = b256["landmarks_only"]
+    assert lo["outputs_verified"] is True and lo["sub_model_vertices"] > 400 and lo["images_per_sec"] > 1.5 * b256["images_per_sec"]
     assert rnd["two_streams"]["images_per_sec"] > 0.9 * rnd["images_per_sec"]  # two batches in flight: never meaningfully slower than one
     assert d["cpu_baseline_render"]["value"] > 0 and d["cpu_baseline_render"]["cores"] == 1
     assert d["secondary"]["outputs_verified"] is True

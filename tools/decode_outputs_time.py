@@ -20,7 +20,7 @@ for b in [int(x) for x in sys.argv[1:]] or [256]:
     lp = torch.empty((b, 445, 2), dtype=torch.int32, device="cuda")
     cases = {"2d: v3d+proj2+lmk": (_lib.TO_2D, v3, p2, lp), "3d: v3d+proj3+lmk": (0, v3, p3, lp), "3d: v3d+proj3": (0, v3, p3, None),
              "3d: proj3 only": (0, None, p3, None), "3d: v3d only": (0, v3, None, None), "2d: proj2 only": (_lib.TO_2D, None, p2, None),
-             "2d: v3d+proj2": (_lib.TO_2D, v3, p2, None)}
+             "2d: v3d+proj2": (_lib.TO_2D, v3, p2, None), "lmk_px only (sub-model unless DAD3D_LANDMARK_SUBSET=0)": (_lib.TO_2D, None, None, lp)}
     res = []
     for name, (fl, a, q, l) in cases.items():
         call = (hm.flame._handle, p.data_ptr(), b, fl | _lib.MUTATE_PARAMS, a.data_ptr() if a is not None else None,
