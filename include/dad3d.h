@@ -116,6 +116,8 @@ DAD3D_EXPORT int dad3d_flame_num_landmark_vertices(const dad3d_flame* h);
  *   lmk_xy  [B,n,2] fp32 = proj[:, idx, :2]
  *   lmk_px  [B,n,2] int32 = projected.astype(int)[idx]  (truncation)           demo_utils.py:42,46
  * The reference needs two full decodes for verts3d + proj (predictor.py:136-137); this is one.
+ * A call with verts3d == proj == NULL and a landmark output decodes only the vertices the landmark list names (see
+ * dad3d_flame_num_landmark_vertices below): a third to a sixth of the whole-mesh time from batch 256 up.
  * hipGraph: the call may be captured (hipStreamBeginCapture on `stream`) after one warm-up call with the same batch
  * size; a captured launch keeps its hand-off bookkeeping on the device, so the graph can be replayed any number of
  * times and interleaved with direct calls (about 1.6 us slower per launch than a direct call). The raster and
