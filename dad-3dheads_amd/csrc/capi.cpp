@@ -463,9 +463,11 @@ static bool landmark_subset_enabled() {
 }
 
 // (Re)build h->lmk_sub for the list just installed: the model restricted to the distinct vertices the list names, in ascending
-// vertex order, with the list remapped onto it. The basis fragments are copied out of the parent's pack (a column's 416 values do not
-// depend on which tile holds it), so the sub-model multiplies the same numbers in the same order: a landmark-only launch returns the
-// bits the two-role kernel returns for those vertices in a full launch. No sub-model when the list names more than a third of the mesh.
+// vertex order, with the list remapped onto it. The basis fragments are copied out of the parent's packs -- both of them: the
+// pipelined kernel's (20-vertex tiles + the jaw-joint columns) and the two-role kernel's -- and a column's 416 values do not depend
+// on which tile holds it, so the sub-model multiplies the same numbers in the same order on whichever kernel the parent would have
+// taken: a landmark-only launch returns the bits a full-output launch of the same handle returns for those vertices
+// (tests/test_gpu_landmark_subset.py). No sub-model when the list names more than a third of the mesh.
 static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, int n) {
     if (h->lmk_sub) dad3d_flame_destroy(h->lmk_sub);
     h->lmk_sub = nullptr;
@@ -499,6 +501,28 @@ static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, in
                     dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
                 }
     for (int u = 0; u < nu; ++u) std::copy(&w8[(size_t)uniq[u] * 8], &w8[(size_t)uniq[u] * 8 + 8], &w8s[(size_t)u * 8]);
+    // the pipelined kernel's pack of the sub-model: [tile][26][4 waves][64 lanes][4], columns 0..59 = 20 vertices, 60..62 = the jaw joint
+    std::vector<float> sub_pipe;
+    const int nt_pipe = (nu + kPipeTileVerts - 1) / kPipeTileVerts;
+    if (h->c->d_bpack_pipe) {
+        std::vector<float> full_pipe((size_t)h->c->n_tiles_pipe * kPipeKGroups * 4 * 64 * 4);
+        DAD3D_HIP_TRY(hipMemcpy(full_pipe.data(), h->c->d_bpack_pipe, full_pipe.size() * sizeof(float), hipMemcpyDeviceToHost));
+        sub_pipe.assign((size_t)nt_pipe * kPipeKGroups * 4 * 64 * 4, 0.0f);
+        for (int t = 0; t < nt_pipe; ++t)
+            for (int g = 0; g < kPipeKGroups; ++g)
+                for (int w = 0; w < 4; ++w)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int col = w * 16 + (lane & 15), u = t * kPipeTileVerts + col / 3;
+                        int st = 0, scol = col;  // the jaw-joint columns (and the zero pad) are the same in every tile
+                        if (col < 3 * kPipeTileVerts) {
+                            if (u >= nu) continue;
+                            st = uniq[u] / kPipeTileVerts, scol = (uniq[u] % kPipeTileVerts) * 3 + col % 3;
+                        }
+                        const float* src = &full_pipe[((((size_t)st * kPipeKGroups + g) * 4 + scol / 16) * 64 + (scol % 16) + 16 * (lane >> 4)) * 4];
+                        float* dst = &sub_pipe[((((size_t)t * kPipeKGroups + g) * 4 + w) * 64 + lane) * 4];
+                        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+                    }
+    }
     std::vector<int64_t> remapped(n);
     for (int s = 0; s < n; ++s) remapped[s] = where[idx[s]];
     std::vector<int> head2, next;
@@ -516,17 +540,19 @@ static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, in
     q->d_trace = nullptr, q->trace_capacity = 0;
     q->ev_first = q->ev_last = nullptr;
     q->prof_launches = 0;
-    q->kernel_choice = DAD3D_KERNEL_TWO_ROLE;  // no pipelined pack for the sub-model: its tiles walk the batch one after the other
+    q->kernel_choice = h->c->d_bpack_pipe ? DAD3D_KERNEL_AUTO : DAD3D_KERNEL_TWO_ROLE;  // the kernel the parent's full launches take
     q->n_verts = nu;
     q->n_tiles = nt_sub;
     q->n_tiles_pad8 = (nt_sub + 7) / 8 * 8;
     q->n_lmk = n;
     q->c = std::make_shared<FlameConsts>();
     q->c->device = h->device;
+    q->c->n_tiles_pipe = nt_pipe;
     dad3d_status st;
     if ((st = upload(&q->c->d_bpack, sub)) || (st = upload(&q->c->d_jdirs, jdirs)) || (st = upload(&q->c->d_j0, j0)) ||
         (st = upload(&q->c->d_w8, w8s)) || (st = upload(&q->d_lmk_head, head2)) || (st = upload(&q->d_lmk_next, next)) ||
-        (st = upload(&q->d_sync, std::vector<unsigned>(kSyncWords, 0u))) || (st = flame_reserve(q.get(), 1))) {
+        (!sub_pipe.empty() && (st = upload(&q->c->d_bpack_pipe, sub_pipe))) || (st = upload_vtab(q.get(), head2)) ||
+        (st = upload(&q->d_sync, std::vector<unsigned>(kSyncWords, 0u))) || (st = flame_reserve(q.get(), std::max(1, h->cap_nbb)))) {
         dad3d_flame_destroy(q.release());
         return st;
     }
@@ -541,6 +567,12 @@ dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_t* idx, int n
     std::vector<int> head2, next;
     landmark_chains(idx, n, h->n_verts, head2, next);
     DeviceGuard guard(h->device);
+    // the old list's sub-model goes first: if anything below fails, no launch can return (or overrun with) the old list's landmarks
+    if (h->lmk_sub) {
+        DAD3D_HIP_TRY(hipDeviceSynchronize());
+        dad3d_flame_destroy(h->lmk_sub);
+        h->lmk_sub = nullptr;
+    }
     dad3d_status st = install_landmark_lists(h, head2, next, n);
     if (st) return st;
     return build_landmark_subset(h, idx, n);
@@ -566,7 +598,8 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Landmark outputs only (BASELINE configs[3]'s per-GPU work; sharding.ShardedLandmarkDecoder): the sub-model of the listed vertices,
-    // 22 column tiles instead of 240, each workgroup one 64-image block -- unless the caller pinned a kernel (A/B timing, diagnostics).
+    // 23 column tiles instead of 252 with the batch cut into chunks across workgroups (pipe_chunk_half) -- same kernel, same bits as
+    // the landmark rows of a full-output launch -- unless the caller pinned a kernel (A/B timing, diagnostics).
     if (h->lmk_sub && !verts3d && !proj && !posed && (lmk_xy || lmk_px) &&
         (h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice()) == DAD3D_KERNEL_AUTO && !(flags & DAD3D_COMPAT_CROSS_B3) && !h->d_trace) {
         dad3d_status st = decode_impl(h->lmk_sub, params, batch, flags, nullptr, nullptr, lmk_xy, lmk_px, nullptr, stream);
@@ -617,6 +650,8 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         pa.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
         pa.image_size = h->image_size;
         pa.flags = flags & 0xFFu;
+        pa.chunk_half = (h->d_trace || (proj && !(flags & DAD3D_TO_2D))) ? 0 : pipe_chunk_half(pa.n_tiles, pa.n_half);
+        pa.tiles8 = (pa.n_tiles + 7) / 8;
         dad3d_status st = launch_flame_decode_pipe(pa, s);
         if (st) return st;
         if (h->profiling) ++h->prof_launches;
@@ -629,6 +664,9 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     if (nbb > h->cap_nbb) {
         DAD3D_HIP_TRY(hipDeviceSynchronize());
         dad3d_status st = flame_reserve(h, nbb);
+        // a two-role sub-model grows with its parent: a landmark-only launch captured into a graph after a full-output warm-up of the
+        // same batch must not find its scratch too small (it could not allocate there)
+        if (!st && h->lmk_sub && h->lmk_sub->kernel_choice == DAD3D_KERNEL_TWO_ROLE && nbb > h->lmk_sub->cap_nbb) st = flame_reserve(h->lmk_sub, nbb);
         if (st) return st;
     }
     DecodeArgs da{};
@@ -749,6 +787,11 @@ dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned* count) {
     DeviceGuard guard(h->device);
     DAD3D_HIP_TRY(hipDeviceSynchronize());
     DAD3D_HIP_TRY(hipMemcpy(count, h->d_sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (h->lmk_sub) {  // landmark-only launches of a model the pipelined kernel does not cover run the two-role kernel there
+        unsigned sub = 0;
+        DAD3D_HIP_TRY(hipMemcpy(&sub, h->lmk_sub->d_sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+        *count += sub;
+    }
     return DAD3D_OK;
 }
 

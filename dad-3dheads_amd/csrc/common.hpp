@@ -141,7 +141,15 @@ struct PipeArgs {
     int n_params, batch, n_half, n_tiles, n_verts, n_lmk;
     float image_size;
     unsigned flags;
+    int chunk_half, tiles8;  // > 0: workgroup = (tile, chunk of chunk_half half-blocks), tiles8 = ceil(n_tiles / 8) (pipe_chunking)
 };
+// Models of few tiles (the landmark sub-model): how many half-blocks a workgroup takes so that the (tile, chunk) grid fills the
+// 32 CUs of each XCD at most once. 0: one workgroup per tile walks the whole batch (the whole mesh: 252 tiles on 256 CUs).
+inline int pipe_chunk_half(int n_tiles, int n_half) {
+    const int tiles8 = (n_tiles + 7) / 8, max_chunks = 32 / tiles8;
+    if (max_chunks < 2 || n_half < 2) return 0;
+    return (n_half + max_chunks - 1) / max_chunks;
+}
 dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s);
 size_t flame_decode_pipe_lds_bytes();
 

@@ -212,7 +212,11 @@ __device__ __forceinline__ void gemm_groups(const float* afrag, const float4 (&b
 // (Measured and dropped, profiles/r04_kernel_log.md: a launch of 33..64 images as ONE pass of four row blocks over both A images,
 // all eight waves finishing both half-blocks -- 13.2 us at B = 64 against 12.8 for the two-phase pipeline: every store of the
 // launch then leaves at the very end.)
-template <bool TO2D>
+// CHUNKED (models of few tiles: the landmark sub-model's 23 for the 445 list): the batch is cut into chunks of a.chunk_half
+// half-blocks and a workgroup is one (tile, chunk) -- the kernel below on rows [b0, b0 + chunk) with every pointer moved there, so a
+// row's results are the bits of an unchunked launch. Workgroup id -> XCD id % 8 is the observed placement (MI355X_MICROARCH.md,
+// "for speed only"): the chunks of one tile sit on ONE XCD and its basis slice crosses the fabric once, not once per chunk.
+template <bool TO2D, bool CHUNKED>
 __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* abuf = smem + Lds::a_off;
@@ -221,7 +225,21 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     lds_int* parts = (lds_int*)(smem + Lds::y_off);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, v0 = tile * TV;
+    int tile_id = blockIdx.x;
+    if (CHUNKED) {
+        const int slot = blockIdx.x >> 3;
+        tile_id = (slot % a.tiles8) * 8 + (blockIdx.x & 7);
+        if (tile_id >= a.n_tiles) return;
+        const int b0 = (slot / a.tiles8) * a.chunk_half * HB;
+        a.params += (size_t)b0 * a.n_params;
+        if (a.verts3d) a.verts3d += (size_t)b0 * a.n_verts * 3;
+        if (a.proj) a.proj += (size_t)b0 * a.n_verts * (TO2D ? 2 : 3);
+        if (a.lmk_xy) a.lmk_xy += (size_t)b0 * a.n_lmk * 2;
+        if (a.lmk_px) a.lmk_px += (size_t)b0 * a.n_lmk * 2;
+        a.batch = min(a.batch - b0, a.chunk_half * HB);
+        a.n_half = (a.batch + HB - 1) / HB;
+    }
+    const int tile = tile_id, v0 = tile * TV;
     const int H = a.n_half, B = a.batch, P = a.n_params;
     unsigned long long* trace = a.trace ? a.trace + ((size_t)tile * 8 + wave) * 32 : nullptr;
     auto stamp = [&](int slot) {
@@ -544,13 +562,19 @@ dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s) {
     const int dev = PerDeviceOnce::current();
     const size_t lds = flame_decode_pipe_lds_bytes();
     if (!attr_done.done(dev)) {
-        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_pipe_kernel<true>),
-                              reinterpret_cast<const void*>(&flame_decode_pipe_kernel<false>)})
+        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_pipe_kernel<true, false>),
+                              reinterpret_cast<const void*>(&flame_decode_pipe_kernel<false, false>),
+                              reinterpret_cast<const void*>(&flame_decode_pipe_kernel<true, true>)})
             DAD3D_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done.set(dev);
     }
-    if (a.flags & DAD3D_TO_2D) hipLaunchKernelGGL(flame_decode_pipe_kernel<true>, dim3(a.n_tiles), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(flame_decode_pipe_kernel<false>, dim3(a.n_tiles), dim3(512), lds, s, a);
+    // without a projection output the two instantiations differ in nothing that runs
+    const bool to2d = (a.flags & DAD3D_TO_2D) || !a.proj;
+    if (a.chunk_half > 0 && to2d) {
+        const int n_chunks = (a.n_half + a.chunk_half - 1) / a.chunk_half;
+        hipLaunchKernelGGL((flame_decode_pipe_kernel<true, true>), dim3(8 * a.tiles8 * n_chunks), dim3(512), lds, s, a);
+    } else if (to2d) hipLaunchKernelGGL((flame_decode_pipe_kernel<true, false>), dim3(a.n_tiles), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((flame_decode_pipe_kernel<false, false>), dim3(a.n_tiles), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

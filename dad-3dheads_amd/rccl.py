@@ -60,7 +60,10 @@ def _device_copy(dst: int, src: int, nbytes: int, stream: int) -> None:
     """hipMemcpyAsync device-to-device on a raw stream (the runtime PyTorch-ROCm already loaded)."""
     global _hip
     if _hip is None:
-        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        # the copy bundled with the PyTorch-ROCm wheel; a build linked against the system runtime has it on the loader path instead
+        # (either way this is the library the process has already mapped: dlopen returns that handle)
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        hip = C.CDLL(bundled if os.path.isfile(bundled) else "libamdhip64.so")
         hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         _hip = hip
     status = _hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, 3, C.c_void_p(stream))  # 3 = hipMemcpyDeviceToDevice

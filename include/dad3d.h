@@ -102,10 +102,11 @@ DAD3D_EXPORT dad3d_status dad3d_flame_set_landmarks(dad3d_flame* h, const int64_
 DAD3D_EXPORT int dad3d_flame_num_landmarks(const dad3d_flame* h);
 /* Landmark-only launches (every vertex output NULL, a landmark output given -- BASELINE configs[3]'s per-GPU work, the landmark-only fast
  * path of SURVEY 7.1) run on the SUB-MODEL of the distinct vertices the list names, built by dad3d_flame_set_landmarks: 445 of 5023 vertices
- * = 22 column tiles instead of 240, the same per-vertex arithmetic on the same basis values (bit-identical to what the two-role kernel
- * returns for those vertices in a full launch). This returns the number of vertices of that sub-model, 0 when there is none (empty list, a
- * list naming more than a third of the mesh, DAD3D_LANDMARK_SUBSET=0). A handle pinned with dad3d_flame_select_kernel(TWO_ROLE / PIPELINED)
- * or tracing decodes the whole mesh for such a launch like for any other. */
+ * = 23 column tiles instead of 252, with the batch cut into chunks across workgroups so that the launch still fills the GPU. Same kernel,
+ * same basis values in the same order: lmk_xy / lmk_px of such a launch are BIT-IDENTICAL to those of a full-output launch of the same
+ * handle, at every batch size (tests/test_gpu_landmark_subset.py). This returns the number of vertices of that sub-model, 0 when there is
+ * none (empty list, a list naming more than a third of the mesh, DAD3D_LANDMARK_SUBSET=0). A handle pinned with
+ * dad3d_flame_select_kernel(TWO_ROLE / PIPELINED) or tracing decodes the whole mesh for such a launch like for any other. */
 DAD3D_EXPORT int dad3d_flame_num_landmark_vertices(const dad3d_flame* h);
 
 /* One fused decode of B parameter rows. Any output pointer may be NULL (not produced).
@@ -117,7 +118,7 @@ DAD3D_EXPORT int dad3d_flame_num_landmark_vertices(const dad3d_flame* h);
  *   lmk_px  [B,n,2] int32 = projected.astype(int)[idx]  (truncation)           demo_utils.py:42,46
  * The reference needs two full decodes for verts3d + proj (predictor.py:136-137); this is one.
  * A call with verts3d == proj == NULL and a landmark output decodes only the vertices the landmark list names (see
- * dad3d_flame_num_landmark_vertices below): a third to a sixth of the whole-mesh time from batch 256 up.
+ * dad3d_flame_num_landmark_vertices above), with the same bits a full-output launch returns for them.
  * hipGraph: the call may be captured (hipStreamBeginCapture on `stream`) after one warm-up call with the same batch
  * size; a captured launch keeps its hand-off bookkeeping on the device, so the graph can be replayed any number of
  * times and interleaved with direct calls (about 1.6 us slower per launch than a direct call). The raster and

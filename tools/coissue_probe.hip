@@ -17,17 +17,37 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// -DPROBE_MFMA=0 (default): the streaming wave issues v_mfma_f32_16x16x4_f32; 1: v_mfma_f32_16x16x32_bf16; 2: v_mfma_f32_32x32x16_bf16
+#ifndef PROBE_MFMA
+#define PROBE_MFMA 0
+#endif
+#if PROBE_MFMA == 0
+typedef f32x4 acc_t;
+#define A_MFMA(ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, ACC, 0, 0, 0)
+static const char* kMfmaName = "v_mfma_f32_16x16x4_f32";
+#elif PROBE_MFMA == 1
+typedef f32x4 acc_t;
+#define A_MFMA(ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, ACC, 0, 0, 0)
+static const char* kMfmaName = "v_mfma_f32_16x16x32_bf16";
+#else
+typedef f32x16 acc_t;
+#define A_MFMA(ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, ACC, 0, 0, 0)
+static const char* kMfmaName = "v_mfma_f32_32x32x16_bf16";
+#endif
 
 enum Cls {
     IDLE, FMA, ADDF, MULF, PKFMA, PKMUL, MAXF, IADD, MAD24, LSHL, ANDB, MOV, CNDMASK, CVTI, EXPF, RCPF, SQRTF,
-    RFL, BPERM, DSR128, DSR32, DSW128, DSW32, GLD128, GLD32, GST128, SADD, SMUL, SLOAD, MFMAB, NCLS
+    RFL, BPERM, DSR128, DSR32, DSW128, DSW32, GLD128, GLD32, GST128, SADD, SMUL, SLOAD, MFMAB, CVTPK, PERM, NCLS
 };
 static const char* kName[NCLS] = {
     "idle (s_sleep)", "v_fma_f32", "v_add_f32", "v_mul_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_max_f32", "v_add_u32",
     "v_mad_u32_u24", "v_lshlrev_b32", "v_and_b32", "v_mov_b32", "v_cndmask_b32", "v_cvt_i32_f32", "v_exp_f32", "v_rcp_f32",
     "v_sqrt_f32", "v_readfirstlane_b32", "ds_bpermute_b32", "ds_read_b128", "ds_read_b32", "ds_write_b128", "ds_write_b32",
     "global_load_dwordx4", "global_load_dword", "global_store_dwordx4", "s_add_u32", "s_mul_i32", "s_load_dwordx4",
-    "v_mfma_f32_16x16x4_f32"};
+    "v_mfma_f32_16x16x4_f32", "v_cvt_pk_bf16_f32", "v_perm_b32"};
 
 struct Regs {
     float x[8];
@@ -52,6 +72,8 @@ __device__ __forceinline__ void eight(Regs& r, float a, float b, unsigned lds_ad
     else if constexpr (C == MAD24) { E8(asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]))) }
     else if constexpr (C == LSHL) { E8(asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r.u[i]))) }
     else if constexpr (C == ANDB) { E8(asm volatile("v_and_b32 %0, %0, %1" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]))) }
+    else if constexpr (C == CVTPK) { E8(asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r.u[i]) : "v"(r.x[i]), "v"(r.x[(i + 4) & 7]))) }
+    else if constexpr (C == PERM) { E8(asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]), "v"(r.u[(i + 2) & 7]))) }
     else if constexpr (C == MOV) { E8(asm volatile("v_mov_b32 %0, %1" : "=v"(r.u[i]) : "v"(r.u[(i + 4) & 7]))) }
     else if constexpr (C == CNDMASK) { E8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]) : "vcc")) }
     else if constexpr (C == CVTI) { E8(asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(r.u[i]) : "v"(r.x[i]))) }
@@ -118,18 +140,20 @@ __global__ __launch_bounds__(512, 1) void beside(Out* out, float* sink, const f3
     Out* o = out + blockIdx.x;
     if (lane == 0) o->hwid[wave] = hw_id();
     float a = 1.0f + lane * 1e-3f, b = 0.999f;
+    bf16x8 fa, fb;
+    for (int i = 0; i < 8; ++i) fa[i] = (__bf16)(a + i), fb[i] = (__bf16)(b - 0.01f * i);
     if (wave < 4) {
         if (b_alone) return;
         if (APRIO > 0) __builtin_amdgcn_s_setprio(3);
-        f32x4 acc[4] = {};
+        acc_t acc[4] = {};
         const unsigned long long t0 = __builtin_readcyclecounter();
         for (int it = 0; it < n_mfma16; ++it) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[3], 0, 0, 0);
+                A_MFMA(acc[0]);
+                A_MFMA(acc[1]);
+                A_MFMA(acc[2]);
+                A_MFMA(acc[3]);
             }
         }
         const unsigned long long t1 = __builtin_readcyclecounter();
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void beside(Out* out, float* sink, const f3
         }
         float r = 0;
         for (int m = 0; m < 4; ++m) r += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
-        sink[blockIdx.x * 512 + threadIdx.x] = r;
+        sink[blockIdx.x * 512 + threadIdx.x] = r + (float)fa[0];
     } else {
         if (APRIO < 0) __builtin_amdgcn_s_setprio(3);
         Regs r;
@@ -190,26 +214,35 @@ __global__ __launch_bounds__(256, 1) void own(Out* out, float* sink, const f32x4
     const unsigned lds_addr = (unsigned)(lane * 16 + wave * 8192);
     const f32x4* gp = gsrc + (size_t)(blockIdx.x * 4 + wave) * 512 + lane;
     f32x4* gst = gdst + (size_t)(blockIdx.x * 4 + wave) * 512 + lane;
-    f32x4 acc[4] = {};
+    bf16x8 fa, fb;
+    for (int i = 0; i < 8; ++i) fa[i] = (__bf16)(a + i), fb[i] = (__bf16)(b - 0.01f * i);
+    acc_t acc[4] = {};
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < n_mfma16; ++it) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            acc[s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[s & 3], 0, 0, 0);
+            A_MFMA(acc[s & 3]);
 #pragma unroll
             for (int k = 0; k < (K > 0 ? K : ((s % (K < 0 ? -K : 1)) == 0 ? 1 : 0)); ++k) {  // K < 0: one every -K MFMAs
                 const int i = (K > 0 ? s * K + k : s / (K < 0 ? -K : 1)) & 7;
                 if constexpr (C == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r.x[i]) : "v"(a), "v"(b));
                 else if constexpr (C == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(r.p[i]) : "v"(r.p[(i + 4) & 7]));
                 else if constexpr (C == IADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]));
+                else if constexpr (C == ADDF) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r.x[i]) : "v"(a));
+                else if constexpr (C == ANDB) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]));
+                else if constexpr (C == LSHL) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r.u[i]) : "v"(r.u[(i + 4) & 7]));
+                else if constexpr (C == CVTPK) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r.u[i]) : "v"(r.x[i]), "v"(r.x[(i + 4) & 7]));
+                else if constexpr (C == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r.u[i]) : "v"(r.u[(i + 4) & 7]), "v"(r.u[(i + 2) & 7]));
+                else if constexpr (C == GST128) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(gst + 64 * i), "v"(r.q[i]) : "memory");
+                else if constexpr (C == DSR32) asm volatile("ds_read_b32 %0, %1" : "+v"(r.u[i]) : "v"((lds_addr >> 2) + 256u * i));
                 else if constexpr (C == DSR128) asm volatile("ds_read_b128 %0, %1" : "+v"(r.q[i]) : "v"(lds_addr + 1024u * i));
                 else if constexpr (C == DSW128) asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr + 1024u * i), "v"(r.q[(i + 4) & 7]) : "memory");
                 else if constexpr (C == GLD128) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r.q[i]) : "v"(gp + 64 * i));
                 else if constexpr (C == SADD) asm volatile("s_add_u32 %0, %0, %1" : "+s"(r.s[i]) : "s"(r.s[(i + 4) & 7]) : "scc");
             }
         }
-        if constexpr (C == DSR128 || C == DSW128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (C == GLD128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (C == DSR128 || C == DSW128 || C == DSR32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (C == GLD128 || C == GST128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (lane == 0) out[blockIdx.x].a_cycles[wave] = t1 - t0;
@@ -226,7 +259,7 @@ static float* d_sink;
 static f32x4 *d_src, *d_dst;
 static const int kBlocks = 64, kMfma16 = 256;  // 4096 MFMAs per A wave ~ 131 k cycles
 static const size_t kLds = (32768 + 128) * 4;
-static double g_base = 0;
+static double g_base = 0, g_own_base = 0;
 
 template <int C, int APRIO, int SPARSE>
 static void run_beside(bool print_hw = false) {
@@ -268,8 +301,9 @@ static void run_own() {
     double cyc = 0;
     for (auto& o : h) for (int w = 0; w < 4; ++w) cyc += o.a_cycles[w];
     const double per = K > 0 ? (double)K : K < 0 ? 1.0 / -K : 1.0;
-    printf("own stream: %5.2f x %-22s per MFMA: %6.2f cyc/MFMA (+%.2f per instruction)\n", per, kName[C], cyc / (kBlocks * 4.0) / (16.0 * kMfma16),
-           (cyc / (kBlocks * 4.0) / (16.0 * kMfma16) - 32.0) / per);
+    const double per_mfma = cyc / (kBlocks * 4.0) / (16.0 * kMfma16);
+    if (C == IDLE) g_own_base = per_mfma;
+    printf("own stream: %5.2f x %-22s per MFMA: %6.2f cyc/MFMA (+%.2f per instruction)\n", per, kName[C], per_mfma, (per_mfma - g_own_base) / per);
     fflush(stdout);
 }
 
@@ -287,8 +321,29 @@ int main() {
     hipMalloc(&d_src, (size_t)kBlocks * 4 * 512 * 16 + 65536);
     hipMalloc(&d_dst, (size_t)kBlocks * 4 * 512 * 16 + 65536);
     hipMemset(d_src, 0, (size_t)kBlocks * 4 * 512 * 16 + 65536);
-    printf("# part 1: class X from a second wave on the SIMD of a streaming v_mfma_f32_16x16x4_f32 wave (%d workgroups x 8 waves)\n", kBlocks);
+    printf("# part 1: class X from a second wave on the SIMD of a streaming %s wave (%d workgroups x 8 waves)\n", kMfmaName, kBlocks);
     run_beside<IDLE, 0, 0>(true);
+#if PROBE_MFMA != 0
+    all_beside<FMA>(); all_beside<ADDF>(); all_beside<ANDB>(); all_beside<LSHL>(); all_beside<CVTPK>(); all_beside<PERM>(); all_beside<MOV>();
+    all_beside<DSR128>(); all_beside<DSW128>(); all_beside<GLD128>(); all_beside<GST128>();
+    printf("# part 2: the same classes inside the MFMA wave's own instruction stream (one wave per SIMD)\n");
+    run_own<IDLE, 0>();
+    run_own<FMA, 1>(); run_own<FMA, 2>(); run_own<FMA, 3>(); run_own<FMA, 4>(); run_own<FMA, 6>();
+    run_own<ADDF, 1>(); run_own<ADDF, 2>(); run_own<ADDF, 4>();
+    run_own<ANDB, 1>(); run_own<ANDB, 2>(); run_own<ANDB, 4>();
+    run_own<LSHL, 1>(); run_own<LSHL, 2>(); run_own<LSHL, 4>();
+    run_own<CVTPK, 1>(); run_own<CVTPK, 2>(); run_own<CVTPK, 4>();
+    run_own<PERM, 1>(); run_own<PERM, 2>(); run_own<PERM, 4>();
+    run_own<PKFMA, 1>(); run_own<PKFMA, 2>();
+    run_own<IADD, 1>(); run_own<IADD, 2>(); run_own<IADD, 4>();
+    run_own<DSR128, -4>(); run_own<DSR128, -2>(); run_own<DSR128, 1>(); run_own<DSR128, 2>();
+    run_own<DSR32, 1>(); run_own<DSR32, 2>();
+    run_own<DSW128, -8>(); run_own<DSW128, -4>(); run_own<DSW128, -2>(); run_own<DSW128, 1>();
+    run_own<GLD128, -8>(); run_own<GLD128, -4>();
+    run_own<GST128, -8>(); run_own<GST128, -4>(); run_own<GST128, -2>();
+    run_own<SADD, 2>(); run_own<SADD, 6>();
+    return 0;
+#endif
     all_beside<FMA>(); all_beside<ADDF>(); all_beside<MULF>(); all_beside<MAXF>(); all_beside<PKFMA>(); all_beside<PKMUL>();
     all_beside<IADD>(); all_beside<MAD24>(); all_beside<LSHL>(); all_beside<ANDB>(); all_beside<MOV>(); all_beside<CNDMASK>();
     all_beside<CVTI>(); all_beside<EXPF>(); all_beside<RCPF>(); all_beside<SQRTF>(); all_beside<RFL>(); all_beside<BPERM>();
