@@ -78,6 +78,9 @@ struct dad3d_flame {
     bool profiling = false;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
     uint64_t trace_capacity = 0;
+    char* d_split_a = nullptr;    // scratch of the bf16x3 split kernel (flame_decode_split.hip): params rows as bf16 planes,
+    float* d_split_c = nullptr;   // per-image constants; split_cap phases of 16 images
+    int split_cap = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
     // Landmark-only launches (SURVEY 7.1 "landmark-only fast path"; BASELINE configs[3]'s per-GPU work): a second handle over the
@@ -92,6 +95,7 @@ static int decode_kernel_choice() {
         const char* e = getenv("DAD3D_DECODE_KERNEL");
         if (!e) return 0;
         if (e[0] == 'v' && e[1] == '1') return DAD3D_KERNEL_TWO_ROLE;
+        if (std::strcmp(e, "split") == 0) return DAD3D_KERNEL_SPLIT_BF16;
         return std::strcmp(e, "force_pipe") == 0 ? DAD3D_KERNEL_PIPELINED : DAD3D_KERNEL_AUTO;  // "pipe" = the default
     }();
     return choice;
@@ -366,7 +370,7 @@ void dad3d_flame_destroy(dad3d_flame* h) {
     h->lmk_sub = nullptr;
     DeviceGuard guard(h->device);
     for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials,
-                    (void*)h->d_grad_partials, (void*)h->d_vtab})
+                    (void*)h->d_grad_partials, (void*)h->d_vtab, (void*)h->d_split_a, (void*)h->d_split_c})
         if (p) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
@@ -390,6 +394,7 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->grad_cap = 0;
     h->arrive_total = 0;
     h->cap_nbb = 0;
+    h->d_split_a = nullptr, h->d_split_c = nullptr, h->split_cap = 0;
     h->profiling = false;
     h->d_trace = nullptr;
     h->ev_first = h->ev_last = nullptr;
@@ -536,6 +541,7 @@ static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, in
     q->d_sync = nullptr;
     q->d_bwd_partials = q->d_grad_partials = nullptr;
     q->bwd_cap = 0, q->grad_cap = 0, q->arrive_total = 0, q->cap_nbb = 0;
+    q->d_split_a = nullptr, q->d_split_c = nullptr, q->split_cap = 0;
     q->profiling = false;
     q->d_trace = nullptr, q->trace_capacity = 0;
     q->ev_first = q->ev_last = nullptr;
@@ -598,7 +604,7 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Landmark outputs only (BASELINE configs[3]'s per-GPU work; sharding.ShardedLandmarkDecoder): the sub-model of the listed vertices,
-    // 23 column tiles instead of 252 with the batch cut into chunks across workgroups (pipe_chunk_half) -- same kernel, same bits as
+    // 23 column tiles instead of 252 with the batch cut into chunks across workgroups (pipe_chunking) -- same kernel, same bits as
     // the landmark rows of a full-output launch -- unless the caller pinned a kernel (A/B timing, diagnostics).
     if (h->lmk_sub && !verts3d && !proj && !posed && (lmk_xy || lmk_px) &&
         (h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice()) == DAD3D_KERNEL_AUTO && !(flags & DAD3D_COMPAT_CROSS_B3) && !h->d_trace) {
@@ -624,9 +630,51 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     const int choice = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
-    if (choice == DAD3D_KERNEL_PIPELINED && !pipe_covers) {
-        set_error("dad3d_flame_decode: the pipelined kernel does not cover this launch (model, flags or output size)");
+    if ((choice == DAD3D_KERNEL_PIPELINED || choice == DAD3D_KERNEL_SPLIT_BF16) && !pipe_covers) {
+        set_error("dad3d_flame_decode: the %s kernel does not cover this launch (model, flags or output size)",
+                  choice == DAD3D_KERNEL_PIPELINED ? "pipelined" : "bf16x3 split");
         return DAD3D_E_UNSUPPORTED;
+    }
+    if (choice == DAD3D_KERNEL_SPLIT_BF16) {
+        // The gated bf16x3 exact-product split (flame_decode_split.hip): same model coverage, same pack, same epilogue as the pipelined
+        // kernel; the contraction differs (and is the more accurate of the two: profiles/r06_split_error.md). Two launches.
+        DAD3D_REQUIRE(!h->d_trace, "dad3d_flame_decode: the bf16x3 split kernel has no trace stamps");
+        const int n_phase = (batch + kSplitRows - 1) / kSplitRows;
+        if (n_phase > h->split_cap) {
+            hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+            if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
+            DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone,
+                          "the first split-kernel decode of a handle (and the first at a larger batch) allocates: run it once before capturing a graph");
+            DAD3D_HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(h->d_split_a), (void)hipFree(h->d_split_c);
+            h->d_split_a = nullptr, h->d_split_c = nullptr, h->split_cap = 0;
+            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitImageBytes));
+            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_c), (size_t)n_phase * kSplitRows * 24 * sizeof(float)));
+            h->split_cap = n_phase;
+        }
+        SplitArgs sa{};
+        sa.params = params;
+        sa.bpack = h->c->d_bpack_pipe;
+        sa.vtab = h->d_vtab;
+        sa.lmk_next = h->d_lmk_next;
+        sa.verts3d = verts3d;
+        sa.proj = proj;
+        sa.lmk_xy = lmk_xy;
+        sa.lmk_px = lmk_px;
+        sa.aplanes = h->d_split_a;
+        sa.consts = h->d_split_c;
+        sa.n_params = h->lay.n_params;
+        sa.batch = batch;
+        sa.n_phase = n_phase;
+        sa.n_tiles = h->c->n_tiles_pipe;
+        sa.n_verts = h->n_verts;
+        sa.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
+        sa.image_size = h->image_size;
+        sa.flags = flags & 0xFFu;
+        dad3d_status st = launch_flame_decode_split(sa, s);
+        if (st) return st;
+        if (h->profiling) ++h->prof_launches;
+        return DAD3D_OK;
     }
     if (pipe_covers && choice != DAD3D_KERNEL_TWO_ROLE) {
         DAD3D_REQUIRE(!h->d_trace || h->trace_capacity >= trace_entries_pipe(h), "dad3d_flame_decode: the trace buffer holds %llu entries, "
@@ -650,8 +698,8 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         pa.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
         pa.image_size = h->image_size;
         pa.flags = flags & 0xFFu;
-        pa.chunk_half = (h->d_trace || (proj && !(flags & DAD3D_TO_2D))) ? 0 : pipe_chunk_half(pa.n_tiles, pa.n_half);
-        pa.tiles8 = (pa.n_tiles + 7) / 8;
+        pa.n_chunks = 1;
+        if (!h->d_trace && (!proj || (flags & DAD3D_TO_2D))) pipe_chunking(pa.n_tiles, pa.n_half, &pa.chunk_half, &pa.n_chunks, &pa.wg_per_xcd);
         dad3d_status st = launch_flame_decode_pipe(pa, s);
         if (st) return st;
         if (h->profiling) ++h->prof_launches;
@@ -777,7 +825,7 @@ dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batc
 }
 
 dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which) {
-    DAD3D_REQUIRE(h && which >= DAD3D_KERNEL_AUTO && which <= DAD3D_KERNEL_PIPELINED, "dad3d_flame_select_kernel: bad argument");
+    DAD3D_REQUIRE(h && which >= DAD3D_KERNEL_AUTO && which <= DAD3D_KERNEL_SPLIT_BF16, "dad3d_flame_select_kernel: bad argument");
     h->kernel_choice = which;
     return DAD3D_OK;
 }

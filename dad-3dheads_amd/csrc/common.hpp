@@ -141,17 +141,46 @@ struct PipeArgs {
     int n_params, batch, n_half, n_tiles, n_verts, n_lmk;
     float image_size;
     unsigned flags;
-    int chunk_half, tiles8;  // > 0: workgroup = (tile, chunk of chunk_half half-blocks), tiles8 = ceil(n_tiles / 8) (pipe_chunking)
+    int chunk_half, n_chunks, wg_per_xcd;  // chunk_half > 0: workgroup = (tile, chunk of chunk_half half-blocks) (pipe_chunking)
 };
-// Models of few tiles (the landmark sub-model): how many half-blocks a workgroup takes so that the (tile, chunk) grid fills the
-// 32 CUs of each XCD at most once. 0: one workgroup per tile walks the whole batch (the whole mesh: 252 tiles on 256 CUs).
-inline int pipe_chunk_half(int n_tiles, int n_half) {
-    const int tiles8 = (n_tiles + 7) / 8, max_chunks = 32 / tiles8;
-    if (max_chunks < 2 || n_half < 2) return 0;
-    return (n_half + max_chunks - 1) / max_chunks;
+// Models of few tiles (the landmark sub-model): cut the batch into as many chunks of whole half-blocks as keep tiles x chunks within
+// the 256 CUs (one workgroup per CU: 152 KB of LDS), dealt to the XCDs in runs of wg_per_xcd <= 32. chunk_half = 0: one workgroup per
+// tile walks the whole batch (the whole mesh: 252 tiles).
+inline void pipe_chunking(int n_tiles, int n_half, int* chunk_half, int* n_chunks, int* wg_per_xcd) {
+    *chunk_half = 0, *n_chunks = 1, *wg_per_xcd = 0;
+    const int max_chunks = 256 / n_tiles;
+    if (max_chunks < 2 || n_half < 2) return;
+    *chunk_half = (n_half + max_chunks - 1) / max_chunks;
+    *n_chunks = (n_half + *chunk_half - 1) / *chunk_half;
+    *wg_per_xcd = (n_tiles * *n_chunks + 7) / 8;
 }
 dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s);
 size_t flame_decode_pipe_lds_bytes();
+
+// The bf16x3 exact-product split of the same decode (flame_decode_split.hip, round 6; gated: DAD3D_KERNEL_SPLIT_BF16). Two launches:
+// a pre-pass that splits the params rows into three bf16 planes and computes the per-image constants once, and the tile kernel, which
+// reads the pipelined kernel's basis pack as it is and walks the batch in phases of 16 images.
+constexpr int kSplitRows = 16;        // images per phase: one MFMA row block
+constexpr int kSplitKGroups = 13;     // K = 416 in MFMA groups of 32
+constexpr int kSplitRowBytes = 848;   // one plane row: 416 bf16 + 16 bytes of padding (conflict-free 16-byte fragment reads)
+constexpr int kSplitImageBytes = 3 * kSplitRows * kSplitRowBytes;  // one phase in HBM and in LDS: [3 planes][16 rows][848]
+struct SplitArgs {
+    float* params;           // [B,P] (tz written when DAD3D_MUTATE_PARAMS)
+    const float* bpack;      // the pipelined kernel's pack (PipeArgs::bpack)
+    const float4* vtab;      // [V] as PipeArgs::vtab
+    const int* lmk_next;     // [n_lmk]
+    float* verts3d;          // [B,V,3] or null
+    float* proj;             // [B,V,2|3] or null
+    float* lmk_xy;           // [B,n_lmk,2] or null
+    int32_t* lmk_px;         // [B,n_lmk,2] or null
+    char* aplanes;           // [n_phase][kSplitImageBytes] scratch: the params rows as bf16 planes (pre-pass -> tile kernel)
+    float* consts;           // [n_phase * 16][24] scratch: per-image constants D 9 | G 9 | s tx ty | pad
+    int n_params, batch, n_phase, n_tiles, n_verts, n_lmk;
+    float image_size;
+    unsigned flags;
+};
+dad3d_status launch_flame_decode_split(const SplitArgs& a, hipStream_t s);
+size_t flame_decode_split_lds_bytes();
 
 // Backward of the per-vertex half of the decode (flame_backward.hip). Per-image constants, natural joint order:
 //   [0,60) A_j rows 0..2 of the relative transforms (j = 0..4, 12 floats each)   [60,69) G row-major   [69] s   [70,72) tx ty

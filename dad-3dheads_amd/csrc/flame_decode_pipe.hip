@@ -36,13 +36,8 @@
 #pragma clang fp contract(off)
 #include "common.hpp"
 #include "flame_math.hpp"
+#include "flame_pipe_epilogue.hpp"
 
-#ifndef DAD3D_PIPE_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no vertex stores, 2 = no epilogue in the GEMM,
-#define DAD3D_PIPE_ABLATE 0  // 4 = no constants rounds after the first. Results wrong, timing meaningful. 0 in the product
-#endif
-#ifndef DAD3D_PIPE_STORE_AUX  // cache policy of the vertex stores (buffer-op aux bits: 1 = sc0, 2 = nt, 16 = sc1). 2 = non-temporal: the
-#define DAD3D_PIPE_STORE_AUX 16 // outputs (105 KB per image) stream through the L2 instead of evicting the basis and piling up dirty lines
-#endif                          // for the end-of-kernel write-back: 21.95 / 38.2 against 23.5 / 40.7 us at B = 128 / 256 (plain stores)
 #ifndef DAD3D_PIPE_STAGER_PRIO  // s_setprio of the stager waves (the mma waves stay at 0). Their instructions are few and every
 #define DAD3D_PIPE_STAGER_PRIO 0  // one of them sits on a latency chain -- but priority 1 measured slower at every size (14.9 / 23.7 / 40.5 / 139.2
                                   // against 14.0 / 22.6 / 39.5 / 138.4 us at B = 64 / 128 / 256 / 1024, same call; 3: as 1)
@@ -52,17 +47,8 @@ namespace dad3d {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B access to a 4-byte aligned address
-typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));  // 12 B store
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8 B store to a 4-byte aligned address
-typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
-typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) int lds_int;
+using namespace pipe;
 
-constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
 constexpr int KG = kPipeKGroups;       // MFMA groups of 16 k
 constexpr int HB = kPipeHalf;          // images per half-block
 constexpr int TV = kPipeTileVerts;     // vertices per tile
@@ -95,66 +81,6 @@ __device__ __forceinline__ void arrive(lds_int* p, int lane) {
 // stagers keep the next A image in flight across it, the mma waves their stores
 __device__ __forceinline__ void phase_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 fma2(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, f32x2{b, b}, c); }
-
-// ---- one (vertex, image): skinning, +MESH_OFFSET_Z, 6-DoF rotation, projection, stores ---------------------------------------------
-struct EpiCtx {  // uniform over the workgroup
-    char *lx, *lp;                    // landmark outputs (float / int pixels) or null
-    const int* lmk_next;
-    float image_size, zsign;
-};
-// One lane's vertex of one image. c0..c5 = the image's constants (D 9 | G 9 | s tx ty), (jx, jy, jz) = its jaw joint, (ex, ey, ez) =
-// v_posed of the vertex; W, w2 = sum of the five skinning weights, the jaw's; lh, ln = first landmark slot of the vertex, the slot
-// chained after it; st3 / stp / stl = store the 3-D vertex / the projection / landmarks (image inside the batch, vertex inside the
-// mesh, output given); vrow = b * V + (a vertex of the tile): the stores go to vertex vrow + VOFF; bnl = b * n_lmk.
-template <bool TO2D, int VOFF>
-__device__ __forceinline__ void finish_vertex(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, float4 c0, float4 c1, float4 c2, float4 c3, float4 c4, float4 c5, float jx, float jy, float jz, float ex, float ey, float ez,
-                                              float W, float w2, int lh, int ln, bool st3, bool stp, bool stl, unsigned vrow, unsigned bnl) {
-    const float sc = c4.z;
-    // smplx lbs steps 5-6 with only the jaw rotating: T.[v;1] = W v + w_jaw (R_jaw - I)(v - J_jaw)
-    const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
-    const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
-    const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
-    const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
-    const float px = pxy.x, py = pxy.y;
-    const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
-    // flame.py:226-228: R.v with R = [b1 b2 b3]
-    const f32x2 rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
-    const float rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
-    // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
-    const f32x2 oxy = (fma2(rxy, sc, f32x2{c4.w, c5.x}) + 1.0f) / 2.0f * cx.image_size;
-    const float ox = oxy.x, oy = oxy.y;
-    // neighbouring lanes = consecutive vertices of one image: contiguous runs per store instruction
-    if (DAD3D_PIPE_ABLATE & 1) {
-        if (ox == 12345.678f) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{rxy.x, rxy.y, rz}), rs3, 0, 0, 0);
-    } else {
-        if (st3)
-            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{rxy.x, rxy.y, rz}), rs3, (int)(vrow * 12u), 12 * VOFF,
-                                                  DAD3D_PIPE_STORE_AUX);
-        if (stp) {
-            if (TO2D) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{ox, oy}), rsp, (int)(vrow * 8u), 8 * VOFF, DAD3D_PIPE_STORE_AUX);
-            } else {
-                const f3u o3 = f3u{ox, oy, cx.zsign * ((__builtin_fmaf(rz, sc, 0.0f) + 1.0f) / 2.0f * cx.image_size)};
-                __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, o3), rsp, (int)(vrow * 12u), 12 * VOFF, DAD3D_PIPE_STORE_AUX);
-            }
-        }
-    }
-    if (stl) {
-        auto put = [&](int slot) {
-            const unsigned off = (bnl + (unsigned)slot) * 8u;
-            if (cx.lx) *reinterpret_cast<f2u*>(cx.lx + off) = f2u{ox, oy};
-            if (cx.lp) *reinterpret_cast<i2u*>(cx.lp + off) = i2u{(int)ox, (int)oy};  // numpy .astype(int): toward zero
-        };
-        put(lh);
-        if (ln >= 0) {  // duplicate indices in the landmark list: the chain goes on (rare; its loads wait, the rest does not)
-            put(ln);
-            for (int slot = cx.lmk_next[ln]; slot >= 0; slot = cx.lmk_next[slot]) put(slot);
-        }
-    }
 }
 
 // ---- the GEMM of one half-block on one mma wave: acc[m] += A[16 m .. 16 m + 16][k] * basis[k][16 columns] --------------------
@@ -212,10 +138,11 @@ __device__ __forceinline__ void gemm_groups(const float* afrag, const float4 (&b
 // (Measured and dropped, profiles/r04_kernel_log.md: a launch of 33..64 images as ONE pass of four row blocks over both A images,
 // all eight waves finishing both half-blocks -- 13.2 us at B = 64 against 12.8 for the two-phase pipeline: every store of the
 // launch then leaves at the very end.)
-// CHUNKED (models of few tiles: the landmark sub-model's 23 for the 445 list): the batch is cut into chunks of a.chunk_half
+// CHUNKED (models of few tiles: the landmark sub-model's 23 for the 445 list): the batch is cut into a.n_chunks chunks of a.chunk_half
 // half-blocks and a workgroup is one (tile, chunk) -- the kernel below on rows [b0, b0 + chunk) with every pointer moved there, so a
-// row's results are the bits of an unchunked launch. Workgroup id -> XCD id % 8 is the observed placement (MI355X_MICROARCH.md,
-// "for speed only"): the chunks of one tile sit on ONE XCD and its basis slice crosses the fabric once, not once per chunk.
+// row's results are the bits of an unchunked launch. Workgroups w = tile * n_chunks + chunk are dealt to the XCDs in runs of a.wg_per_xcd
+// (<= 32, one per CU); workgroup id -> XCD id % 8 is the observed placement (MI355X_MICROARCH.md, "for speed only"): the chunks of one
+// tile sit on one XCD (two at a run's end) and its basis slice crosses the fabric once or twice, not once per chunk.
 template <bool TO2D, bool CHUNKED>
 __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -227,10 +154,10 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_id = blockIdx.x;
     if (CHUNKED) {
-        const int slot = blockIdx.x >> 3;
-        tile_id = (slot % a.tiles8) * 8 + (blockIdx.x & 7);
-        if (tile_id >= a.n_tiles) return;
-        const int b0 = (slot / a.tiles8) * a.chunk_half * HB;
+        const int w = (blockIdx.x & 7) * a.wg_per_xcd + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= a.wg_per_xcd || w >= a.n_tiles * a.n_chunks) return;
+        tile_id = w / a.n_chunks;
+        const int b0 = (w % a.n_chunks) * a.chunk_half * HB;
         a.params += (size_t)b0 * a.n_params;
         if (a.verts3d) a.verts3d += (size_t)b0 * a.n_verts * 3;
         if (a.proj) a.proj += (size_t)b0 * a.n_verts * (TO2D ? 2 : 3);
@@ -571,8 +498,7 @@ dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s) {
     // without a projection output the two instantiations differ in nothing that runs
     const bool to2d = (a.flags & DAD3D_TO_2D) || !a.proj;
     if (a.chunk_half > 0 && to2d) {
-        const int n_chunks = (a.n_half + a.chunk_half - 1) / a.chunk_half;
-        hipLaunchKernelGGL((flame_decode_pipe_kernel<true, true>), dim3(8 * a.tiles8 * n_chunks), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((flame_decode_pipe_kernel<true, true>), dim3(8 * a.wg_per_xcd), dim3(512), lds, s, a);
     } else if (to2d) hipLaunchKernelGGL((flame_decode_pipe_kernel<true, false>), dim3(a.n_tiles), dim3(512), lds, s, a);
     else hipLaunchKernelGGL((flame_decode_pipe_kernel<false, false>), dim3(a.n_tiles), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());

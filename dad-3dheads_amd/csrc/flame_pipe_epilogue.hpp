@@ -1,0 +1,93 @@
+// The per-(vertex, image) finish of the pipelined decode kernels (flame_decode_pipe.hip: fp32 MFMA; flame_decode_split.hip: the
+// bf16x3 exact-product split): skinning with only the jaw rotating, +MESH_OFFSET_Z, 6-DoF rotation, projection, landmark slots, stores.
+// ONE source for both, so that the two differ in the contraction only. Include it under `#pragma clang fp contract(off)`: every copy
+// the compiler inlines has to round identically (the fused multiply-adds are written out).
+// Reference arithmetic: smplx.lbs steps 5-6, model_training/model/flame.py:224-228, model_training/head_mesh.py:39-45,
+// demo_utils.py:42-46 (int truncation of the landmark pixels).
+#pragma once
+#include "common.hpp"
+
+#ifndef DAD3D_PIPE_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no vertex stores, 2 = no epilogue in the GEMM,
+#define DAD3D_PIPE_ABLATE 0  // 4 = no constants rounds after the first. Results wrong, timing meaningful. 0 in the product
+#endif
+#ifndef DAD3D_PIPE_STORE_AUX  // cache policy of the vertex stores (buffer-op aux bits: 1 = sc0, 2 = nt, 16 = sc1). 2 = non-temporal: the
+#define DAD3D_PIPE_STORE_AUX 16 // outputs (105 KB per image) stream through the L2 instead of evicting the basis and piling up dirty lines
+#endif                          // for the end-of-kernel write-back: 21.95 / 38.2 against 23.5 / 40.7 us at B = 128 / 256 (plain stores)
+
+namespace dad3d {
+namespace pipe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 B access to a 4-byte aligned address
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));  // 12 B store
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));  // 8 B store to a 4-byte aligned address
+typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) int lds_int;
+
+constexpr float kMeshOffsetZ = 0.05f;  // flame.py:114
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, f32x2{b, b}, c); }
+
+// ---- one (vertex, image): skinning, +MESH_OFFSET_Z, 6-DoF rotation, projection, stores ---------------------------------------------
+struct EpiCtx {  // uniform over the workgroup
+    char *lx, *lp;                    // landmark outputs (float / int pixels) or null
+    const int* lmk_next;
+    float image_size, zsign;
+};
+// One lane's vertex of one image. c0..c5 = the image's constants (D 9 | G 9 | s tx ty), (jx, jy, jz) = its jaw joint, (ex, ey, ez) =
+// v_posed of the vertex; W, w2 = sum of the five skinning weights, the jaw's; lh, ln = first landmark slot of the vertex, the slot
+// chained after it; st3 / stp / stl = store the 3-D vertex / the projection / landmarks (image inside the batch, vertex inside the
+// mesh, output given); vrow = b * V + (a vertex of the tile): the stores go to vertex vrow + VOFF; bnl = b * n_lmk.
+template <bool TO2D, int VOFF>
+__device__ __forceinline__ void finish_vertex(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, float4 c0, float4 c1, float4 c2, float4 c3, float4 c4, float4 c5, float jx, float jy, float jz, float ex, float ey, float ez,
+                                              float W, float w2, int lh, int ln, bool st3, bool stp, bool stl, unsigned vrow, unsigned bnl) {
+    const float sc = c4.z;
+    // smplx lbs steps 5-6 with only the jaw rotating: T.[v;1] = W v + w_jaw (R_jaw - I)(v - J_jaw)
+    const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
+    const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
+    const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
+    const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
+    const float px = pxy.x, py = pxy.y;
+    const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
+    // flame.py:226-228: R.v with R = [b1 b2 b3]
+    const f32x2 rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
+    const float rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
+    // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+    const f32x2 oxy = (fma2(rxy, sc, f32x2{c4.w, c5.x}) + 1.0f) / 2.0f * cx.image_size;
+    const float ox = oxy.x, oy = oxy.y;
+    // neighbouring lanes = consecutive vertices of one image: contiguous runs per store instruction
+    if (DAD3D_PIPE_ABLATE & 1) {
+        if (ox == 12345.678f) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{rxy.x, rxy.y, rz}), rs3, 0, 0, 0);
+    } else {
+        if (st3)
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{rxy.x, rxy.y, rz}), rs3, (int)(vrow * 12u), 12 * VOFF,
+                                                  DAD3D_PIPE_STORE_AUX);
+        if (stp) {
+            if (TO2D) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{ox, oy}), rsp, (int)(vrow * 8u), 8 * VOFF, DAD3D_PIPE_STORE_AUX);
+            } else {
+                const f3u o3 = f3u{ox, oy, cx.zsign * ((__builtin_fmaf(rz, sc, 0.0f) + 1.0f) / 2.0f * cx.image_size)};
+                __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, o3), rsp, (int)(vrow * 12u), 12 * VOFF, DAD3D_PIPE_STORE_AUX);
+            }
+        }
+    }
+    if (stl) {
+        auto put = [&](int slot) {
+            const unsigned off = (bnl + (unsigned)slot) * 8u;
+            if (cx.lx) *reinterpret_cast<f2u*>(cx.lx + off) = f2u{ox, oy};
+            if (cx.lp) *reinterpret_cast<i2u*>(cx.lp + off) = i2u{(int)ox, (int)oy};  // numpy .astype(int): toward zero
+        };
+        put(lh);
+        if (ln >= 0) {  // duplicate indices in the landmark list: the chain goes on (rare; its loads wait, the rest does not)
+            put(ln);
+            for (int slot = cx.lmk_next[ln]; slot >= 0; slot = cx.lmk_next[slot]) put(slot);
+        }
+    }
+}
+
+}  // namespace pipe
+}  // namespace dad3d

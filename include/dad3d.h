@@ -196,11 +196,17 @@ DAD3D_EXPORT dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned*
  * (csrc/flame_decode_pipe.hip) whenever it covers the launch -- jaw-only model with the dad_3dnet.yaml params layout, inference outputs,
  * no DAD3D_ZERO_ROTATION / DAD3D_COMPAT_CROSS_B3 -- and the two-role kernel (csrc/flame_decode.hip) otherwise; DAD3D_KERNEL_TWO_ROLE
  * forces the latter; DAD3D_KERNEL_PIPELINED returns DAD3D_E_UNSUPPORTED from a decode the pipelined kernel does not cover instead of
- * falling back. The environment variable DAD3D_DECODE_KERNEL=v1|force_pipe sets the process-wide default for handles that have not chosen
- * (A/B timing; anything else = automatic). */
+ * falling back. DAD3D_KERNEL_SPLIT_BF16 (round 6, never chosen automatically) = the same decode with the blend-shape contraction on the
+ * bf16 matrix pipe as an exact-product split (csrc/flame_decode_split.hip): params rows and basis are each split into three bf16
+ * planes with exact residuals and six of the nine plane products are accumulated in fp32 -- measured MORE accurate against float64 than
+ * the fp32 MFMA chain (profiles/r06_split_error.md) and held to the same bars by the same tests, but NOT bit-identical to the default
+ * kernel; same model coverage as the pipelined kernel (DAD3D_E_UNSUPPORTED otherwise), two launches per decode, its first call at a
+ * batch size allocates (warm up before capturing a graph). The environment variable DAD3D_DECODE_KERNEL=v1|force_pipe|split sets the
+ * process-wide default for handles that have not chosen (A/B timing; anything else = automatic). */
 #define DAD3D_KERNEL_AUTO 0
 #define DAD3D_KERNEL_TWO_ROLE 1
 #define DAD3D_KERNEL_PIPELINED 2
+#define DAD3D_KERNEL_SPLIT_BF16 3
 DAD3D_EXPORT dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which);
 /* Diagnostics: a DEVICE buffer of `capacity` uint64 entries that every wave of the decode kernel fills with shader-clock stamps
  * (32 entries per wave; slots 12 / 13 = the 100 MHz wall clock at the wave's start / end); NULL switches it off. The two kernels
