@@ -78,9 +78,8 @@ struct dad3d_flame {
     bool profiling = false;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
     uint64_t trace_capacity = 0;
-    char* d_split_a = nullptr;    // scratch of the bf16x3 split kernel (flame_decode_split.hip): params rows as bf16 planes,
-    float* d_split_c = nullptr;   // per-image constants; split_cap phases of 16 images
-    int split_cap = 0;
+    char* d_split_a = nullptr;    // scratch of the bf16x3 split kernel (flame_decode_split.hip): params rows as bf16 planes + per-image
+    int split_cap = 0;            // constants; split_cap phases of 16 images
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
     // Landmark-only launches (SURVEY 7.1 "landmark-only fast path"; BASELINE configs[3]'s per-GPU work): a second handle over the
@@ -370,7 +369,7 @@ void dad3d_flame_destroy(dad3d_flame* h) {
     h->lmk_sub = nullptr;
     DeviceGuard guard(h->device);
     for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials,
-                    (void*)h->d_grad_partials, (void*)h->d_vtab, (void*)h->d_split_a, (void*)h->d_split_c})
+                    (void*)h->d_grad_partials, (void*)h->d_vtab, (void*)h->d_split_a})
         if (p) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
@@ -394,7 +393,7 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->grad_cap = 0;
     h->arrive_total = 0;
     h->cap_nbb = 0;
-    h->d_split_a = nullptr, h->d_split_c = nullptr, h->split_cap = 0;
+    h->d_split_a = nullptr, h->split_cap = 0;
     h->profiling = false;
     h->d_trace = nullptr;
     h->ev_first = h->ev_last = nullptr;
@@ -541,7 +540,7 @@ static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, in
     q->d_sync = nullptr;
     q->d_bwd_partials = q->d_grad_partials = nullptr;
     q->bwd_cap = 0, q->grad_cap = 0, q->arrive_total = 0, q->cap_nbb = 0;
-    q->d_split_a = nullptr, q->d_split_c = nullptr, q->split_cap = 0;
+    q->d_split_a = nullptr, q->split_cap = 0;
     q->profiling = false;
     q->d_trace = nullptr, q->trace_capacity = 0;
     q->ev_first = q->ev_last = nullptr;
@@ -646,10 +645,10 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
             DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone,
                           "the first split-kernel decode of a handle (and the first at a larger batch) allocates: run it once before capturing a graph");
             DAD3D_HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(h->d_split_a), (void)hipFree(h->d_split_c);
-            h->d_split_a = nullptr, h->d_split_c = nullptr, h->split_cap = 0;
-            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitImageBytes));
-            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_c), (size_t)n_phase * kSplitRows * 24 * sizeof(float)));
+            (void)hipFree(h->d_split_a);
+            h->d_split_a = nullptr, h->split_cap = 0;
+            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitBlockBytes));
+            DAD3D_HIP_TRY(hipMemset(h->d_split_a, 0, (size_t)n_phase * kSplitBlockBytes));  // (the padding is copied into LDS, never read)
             h->split_cap = n_phase;
         }
         SplitArgs sa{};
@@ -662,7 +661,6 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         sa.lmk_xy = lmk_xy;
         sa.lmk_px = lmk_px;
         sa.aplanes = h->d_split_a;
-        sa.consts = h->d_split_c;
         sa.n_params = h->lay.n_params;
         sa.batch = batch;
         sa.n_phase = n_phase;

@@ -163,7 +163,9 @@ size_t flame_decode_pipe_lds_bytes();
 constexpr int kSplitRows = 16;        // images per phase: one MFMA row block
 constexpr int kSplitKGroups = 13;     // K = 416 in MFMA groups of 32
 constexpr int kSplitRowBytes = 848;   // one plane row: 416 bf16 + 16 bytes of padding (conflict-free 16-byte fragment reads)
-constexpr int kSplitImageBytes = 3 * kSplitRows * kSplitRowBytes;  // one phase in HBM and in LDS: [3 planes][16 rows][848]
+constexpr int kSplitPlaneBytes = (3 * kSplitRows * kSplitRowBytes + 1023) / 1024 * 1024;  // a phase's planes [3][16 rows][848], in whole KB
+constexpr int kSplitConstBytes = (kSplitRows * 24 * 4 + 1023) / 1024 * 1024;              // its per-image constants [16][24 floats]
+constexpr int kSplitBlockBytes = kSplitPlaneBytes + kSplitConstBytes;                     // one phase in HBM: planes | constants
 struct SplitArgs {
     float* params;           // [B,P] (tz written when DAD3D_MUTATE_PARAMS)
     const float* bpack;      // the pipelined kernel's pack (PipeArgs::bpack)
@@ -173,8 +175,8 @@ struct SplitArgs {
     float* proj;             // [B,V,2|3] or null
     float* lmk_xy;           // [B,n_lmk,2] or null
     int32_t* lmk_px;         // [B,n_lmk,2] or null
-    char* aplanes;           // [n_phase][kSplitImageBytes] scratch: the params rows as bf16 planes (pre-pass -> tile kernel)
-    float* consts;           // [n_phase * 16][24] scratch: per-image constants D 9 | G 9 | s tx ty | pad
+    char* aplanes;           // [n_phase][kSplitBlockBytes] scratch, pre-pass -> tile kernel: the params rows as bf16 planes, then the
+                             // per-image constants D 9 | G 9 | s tx ty | pad of the phase
     int n_params, batch, n_phase, n_tiles, n_verts, n_lmk;
     float image_size;
     unsigned flags;

@@ -3,25 +3,29 @@
 //
 // Why: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (157 TFLOP/s) -- 8 x 32 cycles per K = 32 of a 16 x 16 tile -- and every VALU
 // instruction beside it costs it ~6 cycles (flame_decode_pipe.hip). The bf16 pipe is 16x faster per instruction and co-issues: measured
-// (tools/coissue_probe.hip -DPROBE_MFMA=1, profiles/r06_coissue_bf16.txt) a second wave's VALU instruction costs a streaming
+// (tools/coissue_probe.hip -DPROBE_MFMA=1, profiles/r06/coissue_bf16_16x16x32.txt) a second wave's VALU instruction costs a streaming
 // v_mfma_f32_16x16x32_bf16 wave 0.15 cycles. So: x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) -- three
 // planes of 8 significant bits each, the residuals EXACT in fp32 -- for the params row and for the basis, and
-//     a.b  ~  a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)                  (the dropped terms are < 2^-24 |a b|)
-// as six MFMAs per K = 32 (6 x 16 cycles instead of 8 x 32), every product exact in the fp32 accumulator, three accumulators by order of
-// magnitude added small-to-large at the end. Measured against float64 on the decode's value ranges (tools/split_probe.hip,
-// profiles/r06_split_error.md): max error 3.0e-8 / rms 5.0e-9 against 9.3e-8 / 1.5e-8 for the fp32 MFMA chain -- the split is the MORE
-// accurate of the two (it accumulates 32 exact products per instruction; the fp32 chain rounds after every one).
+//     a.b  ~  a1 b1 + (a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1)                    (the dropped terms are < 2^-24 |a b|)
+// as six MFMAs per K = 32 (6 x 16 cycles instead of 8 x 32), every product exact in the fp32 accumulator, the large term and the five
+// small ones in separate accumulators added at the end. Measured against float64 (tools/split_probe.hip, profiles/r06_split_error.md):
+// 2-3x CLOSER than the fp32 MFMA chain on every line -- it accumulates 32 exact products per instruction; the fp32 chain rounds after
+// every one.
 //
-// Structure (a rebuild of the pipelined kernel around the new pipe's economics):
+// Structure (a rebuild of the pipelined kernel around the new pipe's economics; the steps are measured in profiles/r06_kernel_log.md):
 //   * a pre-pass kernel (one workgroup per image) splits the params rows ONCE into three bf16 planes laid out as the LDS image of a phase
 //     (16 images), computes the per-image constants (Rodrigues of the jaw, 6-DoF rotation, scale, translation) with the code of the fp32
 //     kernel, and performs the tz := 0 side effect. In the fp32 kernel every one of the 252 workgroups recomputes the constants and would
-//     have to re-split the rows: 5.5 VALU instructions per element x 252, the one thing the matrix pipe's partner wave has no slots for.
-//   * main kernel: one workgroup per tile of 20 vertices (the pipelined kernel's pack, read as it is: no second copy of the basis in HBM,
-//     no extra byte in the start-up stream). Its four mma waves split their basis slice into planes ON ARRIVAL (156 registers for the
-//     launch) and run ds_read_b128 + MFMA over PHASES of 16 images; its four partner waves copy the next phase's planes into LDS and
-//     FINISH the previous phase (skinning, rotation, projection, landmark slots, stores: flame_pipe_epilogue.hpp, shared with the fp32
-//     kernel) -- arithmetic that is free beside the bf16 pipe and cost the fp32 pipe 6 cycles an instruction.
+//     have to re-split the rows: 5.5 VALU instructions per element x 252.
+//   * tile kernel: one workgroup per tile of 20 vertices (the pipelined kernel's pack, read as it is: no second copy of the basis in HBM,
+//     no extra byte in the start-up stream), 8 waves in THREE roles:
+//       - four mma waves, each HALF of K x HALF of the columns (78 MFMAs and 21 fragment reads of 1 KB per phase: with every wave on all
+//         of K for 16 columns the LDS pipe, not the matrix pipe, was the bound), their basis slice split into planes ON ARRIVAL and
+//         register-resident for the launch (156 registers). Their one barrier per phase sits between the last fragment read of the phase
+//         and its last six MFMAs: the next phase's first fragments are in flight while those run, and nothing drains.
+//       - one stager wave: global_load_lds (no registers, no ds_write pass) of the next phase's planes + constants, one window ahead.
+//       - three finisher waves: skinning, rotation, projection, landmark slots, stores of the phase before the last (flame_pipe_epilogue.hpp,
+//         shared with the fp32 kernel), every operand from LDS, lanes = consecutive (image, vertex) pairs.
 //   * the k order inside an MFMA is the pack's: lane (q, n) of group g holds k = 32 g + 16 h + 4 q + i (h = 0, 1; i = 0..3), so the
 //     pre-pass stores a row's element k at position 32 g + 8 q + 4 h + i and both operands are one aligned 16-byte read per lane.
 //
@@ -32,8 +36,8 @@
 #include "flame_pipe_epilogue.hpp"
 
 #ifndef DAD3D_SPLIT_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no finishing, 2 = no staging after the second phase,
-#define DAD3D_SPLIT_ABLATE 0  // 4 = no MFMAs. Results wrong, timing meaningful. 0 in the product
-#endif
+#define DAD3D_SPLIT_ABLATE 0  // 4 = no MFMAs, 8 = no parking, 16 = no fragment prefetch behind the barrier. Results wrong, timing
+#endif                        // meaningful. 0 in the product
 
 namespace dad3d {
 
@@ -42,26 +46,27 @@ namespace {
 using namespace pipe;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TV = kPipeTileVerts;      // vertices per tile
 constexpr int kJawCol = 3 * TV;         // columns 60..62 of a tile: the jaw joint
 constexpr int OS = 76;                  // accumulator tile row stride (floats), as in the fp32 kernel
 constexpr int QB = kSplitRows;          // images per phase: one MFMA row block
-constexpr int KG = kSplitKGroups;       // MFMA groups of 32 k
 constexpr int RS = kSplitRowBytes;      // bytes per plane row: 416 bf16 + 16 bytes (RS / 4 = 212 = 20 (mod 64): sixteen rows' 16-byte
                                         // reads at one offset cover the 64 banks once)
-constexpr int IMG = kSplitImageBytes;   // one phase: [3 planes][16 rows][RS]
-constexpr int IMG16 = IMG / 16;         // ... in 16-byte chunks (2544)
+constexpr int PLN = kSplitPlaneBytes;   // the planes of a phase [3][16 rows][RS], padded to a multiple of 1 KB (one wave's global_load_lds)
+constexpr int CST = kSplitConstBytes;   // its constants [16][24 floats], padded likewise
+constexpr int BLK = kSplitBlockBytes;   // a phase in HBM: planes | constants
 constexpr int kNumBeta = 400;
+constexpr int kPairs = QB * TV;         // (image, vertex) pairs of a phase: 320 = five wave-wide finishing calls
 struct Lds {
-    static constexpr int a_off = 0;                      // [2][IMG]       A planes, double buffered
-    static constexpr int o_off = a_off + 2 * IMG;        // [2][2][QB][OS] accumulators (floats): double buffered x the two K halves
-    static constexpr int v_off = o_off + 2 * 2 * QB * OS * 4;
-    static constexpr int total = v_off;
-    static_assert(total <= 160 * 1024 && o_off % 16 == 0, "LDS budget of one CU");
+    static constexpr int a_off = 0;                          // [3][PLN]         A planes, three images: one multiplied, one landed, one in flight
+    static constexpr int c_off = a_off + 3 * PLN;            // [8][CST]         per-image constants, a ring of eight phases (staged two
+                                                             //                  windows ahead of the GEMM, consumed two behind it)
+    static constexpr int o_off = c_off + 8 * CST;            // [2][2][QB][OS]   accumulators (floats): double buffered x the two K halves
+    static constexpr int v_off = o_off + 2 * 2 * QB * OS * 4;  // [TV] float4    the tile's rows of the vertex table
+    static constexpr int total = v_off + TV * 16;
+    static_assert(total <= 160 * 1024 && c_off % 1024 == 0 && o_off % 16 == 0 && v_off % 16 == 0, "LDS budget of one CU");
 };
 
 __device__ __forceinline__ void phase_barrier() {  // does not drain the wave's global loads / stores (flame_decode_pipe.hip)
@@ -74,6 +79,11 @@ __device__ __forceinline__ f32x8 peel(f32x8 r, bf16x8& plane) {
     return r - __builtin_convertvector(plane, f32x8);
 }
 
+// 1 KB from HBM straight into LDS: lane l's 16 bytes land at lds_base + 16 l (the destination is wave-uniform + lane-linear)
+__device__ __forceinline__ void glds_1k(const char* gsrc_lane, char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
 }  // namespace
 
 // ---- pre-pass: one workgroup per image (rows past the batch: zero planes) --------------------------------------------------------
@@ -81,7 +91,8 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
     const int b = blockIdx.x, t = threadIdx.x, P = a.n_params;
     const bool live = b < a.batch;
     float* prow = a.params + (size_t)min(b, a.batch - 1) * P;
-    char* row = a.aplanes + (size_t)(b / QB) * IMG + (size_t)(b % QB) * RS;
+    char* blk = a.aplanes + (size_t)(b / QB) * BLK;
+    char* row = blk + (size_t)(b % QB) * RS;
     // [400,403) jaw | [403,409) 6-DoF rotation | [409,412) translation | [412] scale   (FlameParams.from_3dmm, flame.py:48-73)
     const float jaw[3] = {prow[kNumBeta], prow[kNumBeta + 1], prow[kNumBeta + 2]};
     float D[9];
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
         rot6_to_matrix_lean(rot6, G);
         const float sp1 = prow[412] + 1.0f;
         const float s = sp1 < 1e-8f ? 1e-8f : sp1;  // head_mesh.py:39 torch.clamp(min=): a NaN scale stays NaN
-        float4* c = reinterpret_cast<float4*>(a.consts + (size_t)b * 24);
+        float4* c = reinterpret_cast<float4*>(blk + PLN + (size_t)(b % QB) * 96);
         c[0] = float4{D[0], D[1], D[2], D[3]};
         c[1] = float4{D[4], D[5], D[6], D[7]};
         c[2] = float4{D[8], G[0], G[1], G[2]};
@@ -127,24 +138,83 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
     }
 }
 
-// Barrier protocol (every wave executes 1 + n_phase phase barriers):
-//   S0      A(0) is in LDS
-//   P(p)    the mma waves have parked phase p, the partner waves have written A(p + 1)
-// Between P(p - 1) and P(p): mma waves multiply phase p out of image p & 1 and park it in tile pair p & 1; partner waves write image
-// (p + 1) & 1 -- last read by GEMM(p - 1) --, request the planes of phase p + 2 and finish phase p - 1 out of tile (p - 1) & 1.
+// Barrier protocol (every wave executes n_phase + 2 phase barriers: S0, B(0) .. B(n_phase - 1), E). Window p = between B(p - 1) and B(p).
+//   S0      A(0) and its constants are in LDS (and the tile's rows of the vertex table)
+//   B(p)    mma waves: every fragment of A(p) has been READ (its last six MFMAs and the parking of tile p follow the barrier);
+//           stager: A(p + 1) and its constants have LANDED (A(p + 2) is in flight); finishers: tile p - 2 has been consumed
+//   E       tile n_phase - 1 is parked
+// mma waves, window p + 1: first fragments of A(p + 1) requested, tail MFMAs of phase p, tile p parked in tile pair p & 1, slots 0..5 of
+// phase p + 1. Stager, window p: requests the planes of phase p + 2 into image (p + 2) % 3 -- last read in front of B(p - 1) -- and its
+// constants into ring slot (p + 2) & 7, then waits for phase p + 1's (requested a window earlier: a global -> LDS round trip is as
+// long as a window). Finishers, window p: tile p - 2 out of tile pair p & 1 (parked behind B(p - 2), visible behind B(p - 1); written
+// next behind B(p)), constants from ring slot (p - 2) & 7 (written next in window p + 4).
 template <bool TO2D>
 __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* abuf = smem + Lds::a_off;
+    char* cring = smem + Lds::c_off;
     float* otile = reinterpret_cast<float*>(smem + Lds::o_off);
+    float4* vt_lds = reinterpret_cast<float4*>(smem + Lds::v_off);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the roles branch and loop on SGPRs, not under exec masks
     const int tile = blockIdx.x, v0 = tile * TV;
     const int NP = a.n_phase, B = a.batch;
 
-    if (wave >= 4) {
-        // ========================================= partner waves: stage A, finish vertices =========================================
-        const int fw = wave - 4, t = tid - 256;
+    if (wave == 4) {
+        // ====================================================== stager wave ===========================================================
+        auto stage = [&](int p) {  // 40 + 2 requests of 1 KB
+            const char* src = a.aplanes + (size_t)p * BLK + 16 * lane;
+            char* dst = abuf + (p % 3) * PLN;
+#if defined(DAD3D_SPLIT_NO_GLDS)  // diagnostics: the same copy through registers -- a SLOW stager, the deterministic repro of section 4 of the log
+#pragma unroll 1
+            for (int i0 = 0; i0 < PLN / 1024; i0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + 1024 * (i0 + i));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(dst + 1024 * (i0 + i) + 16 * lane) = v[i];
+            }
+            for (int i = 0; i < CST / 1024; ++i)
+                *reinterpret_cast<f32x4*>(cring + (p & 7) * CST + 1024 * i + 16 * lane) = *reinterpret_cast<const f32x4*>(src + PLN + 1024 * i);
+#else
+#pragma unroll 8
+            for (int i = 0; i < PLN / 1024; ++i) glds_1k(src + 1024 * i, dst + 1024 * i);
+#pragma unroll
+            for (int i = 0; i < CST / 1024; ++i) glds_1k(src + PLN + 1024 * i, cring + (p & 7) * CST + 1024 * i);
+#endif
+        };
+        // this wave's only vector-memory operations are the 42 requests of a stage, so "phase p + 1 has landed" is a COUNTED wait:
+        // everything but the stage issued after it (requests complete in order)
+        constexpr int kStageOps = PLN / 1024 + CST / 1024;
+        static_assert(kStageOps <= 63, "vmcnt is a 6-bit counter");
+        if (lane < TV) vt_lds[lane] = a.vtab[min(v0 + lane, a.n_verts - 1)];  // (in front of every global_load_lds: one plain load, waited for here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage(0);
+        if (NP > 1) {
+            stage(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStageOps) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        phase_barrier();  // S0
+#pragma unroll 1
+        for (int p = 0; p < NP; ++p) {
+            // image (p + 2) % 3 held phase p - 1: every fragment of it was read in front of B(p - 1)
+            if (p + 2 < NP && (!(DAD3D_SPLIT_ABLATE & 2) || p < 1)) {
+                stage(p + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStageOps) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            phase_barrier();  // B(p)
+        }
+        phase_barrier();  // E
+        return;
+    }
+    if (wave > 4) {
+        // ===================================================== finisher waves =========================================================
+        const int fj = wave - 5;
         const unsigned nl = (unsigned)a.n_lmk;
         EpiCtx cx;
         const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.verts3d), 0, 0x7fffffff, 0x00020000);
@@ -153,77 +223,68 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
         cx.lmk_next = a.lmk_next;
         cx.image_size = a.image_size;
         cx.zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
-        // the planes of a phase are ONE contiguous block in HBM, laid out as the LDS image: a linear copy, 10 x 16 bytes per thread
-        f32x4 pre[10];
-        auto load_a = [&](int p) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.aplanes + (size_t)p * IMG);
+        // The 320 (image, vertex) pairs of a phase as five wave-wide calls, pair = 64 call + lane -> image pair / 20, vertex pair % 20:
+        // neighbouring lanes = consecutive vertices of one image (runs of 240 / 160 contiguous bytes per store instruction). The calls of
+        // phase q go to the three waves in turn, starting one wave further every phase: 2, 2, 1 calls, five per wave over three phases.
+        // One call = 64 pairs: operands of a pair (all from LDS), its arithmetic, its stores. A wave's two calls of a window are
+        // written out side by side -- loads of both, arithmetic of both, stores of both -- so that the second one's LDS round trips and
+        // dependent chains hide behind the first one's (one call alone is ~1.4 k cycles beside the MFMA stream, mostly latency).
+        struct Call {
+            float4 k0, k1, k2, k3, k4, k5, vt;
+            float j0[3], j1[3], e0[3], e1[3];  // jaw joint and v_posed of the pair: partial sums of the two K halves
+            int b, u;
+        };
+        auto load_call = [&](int q, int c, Call& t) {
+            const int pair = 64 * c + lane, i = pair / TV;
+            t.u = pair - TV * i, t.b = q * QB + i;
+            const float4* cp = reinterpret_cast<const float4*>(cring + (q & 7) * CST + i * 96);
+            t.k0 = cp[0], t.k1 = cp[1], t.k2 = cp[2], t.k3 = cp[3], t.k4 = cp[4], t.k5 = cp[5];
+            t.vt = vt_lds[t.u];
+            const float* ot = otile + (q & 1) * (2 * QB * OS) + i * OS;  // partial tile of K half 0; half 1 is QB * OS floats on
 #pragma unroll
-            for (int i = 0; i < 10; ++i) pre[i] = src[min(t + 256 * i, IMG16 - 1)];  // (clamped, not branched around: flame_decode_pipe.hip)
-        };
-        auto write_a = [&](int p) {
-            f32x4* dst = reinterpret_cast<f32x4*>(abuf + (p & 1) * IMG);
-#pragma unroll
-            for (int i = 0; i < 10; ++i)
-                if (t + 256 * i < IMG16) dst[t + 256 * i] = pre[i];
-        };
-        load_a(0);
-        // finishing: the wave takes images [4 fw, 4 fw + 4) of every phase, lane = (image fi, vertex fu of sixteen) -> vertices fu and,
-        // for fu < 4, fu + 16; sixteen lanes = sixteen consecutive vertices of one image. Their table rows stay in registers.
-        const int fi = lane & 3, fu = lane >> 2, fli = 4 * fw + fi;
-        const float4 t0 = a.vtab[min(v0 + fu, a.n_verts - 1)];
-        const float4 t1 = a.vtab[min(v0 + min(fu + 16, TV - 1), a.n_verts - 1)];
-        const bool vl0 = v0 + fu < a.n_verts, vl1 = fu < TV - 16 && v0 + fu + 16 < a.n_verts;
-        float4 k0, k1, k2, k3, k4, k5;  // the constants of this lane's image, requested a phase before they are used
-        auto load_consts = [&](int p) {
-            const float4* c = reinterpret_cast<const float4*>(a.consts + (size_t)(p * QB + fli) * 24);
-            k0 = c[0], k1 = c[1], k2 = c[2], k3 = c[3], k4 = c[4], k5 = c[5];
-        };
-        auto finish = [&](int p) {
-            const int b = p * QB + fli;
-            const float* ot = otile + (p & 1) * (2 * QB * OS) + fli * OS;  // partial tile of K half 0; half 1 is QB * OS floats on
-            auto at = [&](int col) { return ot[col] + ot[QB * OS + col]; };
-            const float jx = at(kJawCol), jy = at(kJawCol + 1), jz = at(kJawCol + 2);  // J_jaw of this image, from the GEMM
-            const unsigned vrow = (unsigned)b * (unsigned)a.n_verts + (unsigned)(v0 + fu), bnl = (unsigned)b * nl;
-            {
-                const bool live = b < B && vl0;
-                finish_vertex<TO2D, 0>(cx, rs3, rsp, k0, k1, k2, k3, k4, k5, jx, jy, jz, at(3 * fu), at(3 * fu + 1), at(3 * fu + 2), t0.x, t0.y,
-                                       __float_as_int(t0.z), __float_as_int(t0.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
-                                       live && nl > 0 && __float_as_int(t0.z) >= 0, vrow, bnl);
-            }
-            if (fu < TV - 16) {
-                const int j = fu + 16;
-                const bool live = b < B && vl1;
-                finish_vertex<TO2D, 16>(cx, rs3, rsp, k0, k1, k2, k3, k4, k5, jx, jy, jz, at(3 * j), at(3 * j + 1), at(3 * j + 2), t1.x, t1.y,
-                                        __float_as_int(t1.z), __float_as_int(t1.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
-                                        live && nl > 0 && __float_as_int(t1.z) >= 0, vrow, bnl);
+            for (int k = 0; k < 3; ++k) {
+                t.j0[k] = ot[kJawCol + k], t.j1[k] = ot[QB * OS + kJawCol + k];  // J_jaw of this image, from the GEMM
+                t.e0[k] = ot[3 * t.u + k], t.e1[k] = ot[QB * OS + 3 * t.u + k];
             }
         };
-        write_a(0);
-        if (NP > 1) load_a(1);
-        load_consts(0);
+        auto math_call = [&](const Call& t) {
+            return vertex_math_scalar(cx, t.k0, t.k1, t.k2, t.k3, t.k4, t.k5, t.j0[0] + t.j1[0], t.j0[1] + t.j1[1], t.j0[2] + t.j1[2], t.e0[0] + t.e1[0],
+                                      t.e0[1] + t.e1[1], t.e0[2] + t.e1[2], t.vt.x, t.vt.y);
+        };
+        auto store_call = [&](const Call& t, const VertexOut& o) {
+            const bool live = t.b < B && v0 + t.u < a.n_verts;
+            vertex_store<TO2D, 0>(cx, rs3, rsp, o, __float_as_int(t.vt.z), __float_as_int(t.vt.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
+                                  live && nl > 0 && __float_as_int(t.vt.z) >= 0, (unsigned)t.b * (unsigned)a.n_verts + (unsigned)(v0 + t.u), (unsigned)t.b * nl);
+        };
+        auto finish = [&](int q) {
+            const int c0 = (fj + 3 - q % 3) % 3;  // calls c0 and c0 + 3 (the latter exists for c0 < 2)
+            Call ta, tb;
+            load_call(q, c0, ta);
+            if (c0 + 3 < kPairs / 64) {
+                load_call(q, c0 + 3, tb);
+                const VertexOut oa = math_call(ta), ob = math_call(tb);
+                store_call(ta, oa);
+                store_call(tb, ob);
+            } else {
+                store_call(ta, math_call(ta));
+            }
+        };
         phase_barrier();  // S0
 #pragma unroll 1
         for (int p = 0; p < NP; ++p) {
-            if (!(DAD3D_SPLIT_ABLATE & 2) || p < 1) {
-                if (p + 1 < NP) write_a(p + 1);
-                if (p + 2 < NP) load_a(p + 2);
-            }
-            if (p > 0) {
-                if (!(DAD3D_SPLIT_ABLATE & 1)) finish(p - 1);
-                load_consts(p);
-            }
-            phase_barrier();  // P(p)
+            if (p >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) finish(p - 2);
+            phase_barrier();  // B(p)
         }
-        finish(NP - 1);
+        if (NP >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) finish(NP - 2);
+        phase_barrier();  // E
+        if (!(DAD3D_SPLIT_ABLATE & 1)) finish(NP - 1);
         return;
     }
 
     // ==================================================== mma waves ================================================================
     // wave w = (kh = w >> 1, ch = w & 1) multiplies HALF of K against HALF of the tile's columns: bf16 groups [6 kh, 6 kh + 6) x the two
     // 16-column blocks 2 ch, 2 ch + 1, plus the tail group 12 (k = 384..415) for ONE column block -- its block c0 = 2 ch + kh; the other
-    // is c1 = 2 ch + 1 - kh. Against "every wave all of K for its 16 columns" this halves the LDS reads of the A planes (21 fragment
-    // reads of 1 KB per wave and phase instead of 39: the LDS pipe, not the matrix pipe, bounded that form -- profiles/r06_kernel_log.md),
-    // with the same 78 MFMAs per wave and the same 156 registers of basis planes. The two K halves meet in the epilogue: partial tile kh.
+    // is c1 = 2 ch + 1 - kh. The two K halves meet in the finishers: partial tile kh.
     // The pack holds, for MFMA group G of 16 k and column block c, lane (q = lane >> 4, n = lane & 15) the float4 k = 16 G + 4 q + 0..3
     // of column n: groups 2 g and 2 g + 1 are the lane's eight k of bf16 group g.
     const int kh = wave >> 1, ch = wave & 1, c0 = 2 * ch + kh, c1 = 2 * ch + 1 - kh, gbase = 6 * kh;
@@ -249,31 +310,27 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
         r = peel(r, out[1]);
         out[2] = __builtin_convertvector(r, bf16x8);
     };
+    auto read_frags = [&](int p, int g, bf16x8 (&dst)[3]) {
+        const char* ab = afrag0 + (p % 3) * PLN + 64 * g;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(ab + pl * (QB * RS));
+    };
+    bf16x8 af[3];  // the fragments the next MFMAs multiply
 
     // one phase: per column block, hi += a1 b1 and lo += the five smaller products (measured as accurate as three accumulators by order
     // of magnitude, tools/split_probe.hip); FIRST: the basis slice is still arriving and is split slot by slot in front of its first use
-    auto gemm = [&](int p, auto first) {
+    auto phase = [&](int p, auto first) {
         constexpr bool FIRST = decltype(first)::value;
-        const char* ab = afrag0 + (p & 1) * IMG;
         f32x4 hi0 = {0.f, 0.f, 0.f, 0.f}, lo0 = hi0, hi1 = hi0, lo1 = hi0;
-        bf16x8 af[3], an[3] = {};
+        bf16x8 an[3] = {};
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(ab + pl * (QB * RS) + 64 * gbase);
-#pragma unroll
-        for (int sl = 0; sl < 7; ++sl) {
-            if (FIRST) {
-                if (sl < 6) planes(raw[sl][0][0], raw[sl][0][1], bp[sl][0]), planes(raw[sl][1][0], raw[sl][1][1], bp[sl][1]);
-                else planes(rawt[0], rawt[1], bt);
-            }
-            if (sl < 6) {
-                const int gn = sl < 5 ? gbase + sl + 1 : 12;  // the tail group last
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) an[pl] = *reinterpret_cast<const bf16x8*>(ab + pl * (QB * RS) + 64 * gn);
-            }
+        for (int sl = 0; sl < 6; ++sl) {
+            if (FIRST) planes(raw[sl][0][0], raw[sl][0][1], bp[sl][0]), planes(raw[sl][1][0], raw[sl][1][1], bp[sl][1]);
+            read_frags(p, sl < 5 ? gbase + sl + 1 : 12, an);  // the tail group last
             __builtin_amdgcn_sched_barrier(0);
             if ((DAD3D_SPLIT_ABLATE & 4) && !FIRST) {
                 hi0 += __builtin_bit_cast(f32x4, af[0]) + __builtin_bit_cast(f32x4, af[1]) + __builtin_bit_cast(f32x4, af[2]);
-            } else if (sl < 6) {
+            } else {
                 // the two column blocks alternate: no MFMA waits for the one in front of it
                 lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][0][2], lo0, 0, 0, 0);
                 lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][1][2], lo1, 0, 0, 0);
@@ -287,32 +344,47 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
                 lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bp[sl][1][0], lo1, 0, 0, 0);
                 hi0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][0][0], hi0, 0, 0, 0);
                 hi1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][1][0], hi1, 0, 0, 0);
-            } else {  // the tail group, column block c0 only (the MFMAs of the other block's last slot are still in flight behind it)
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[2], lo0, 0, 0, 0);
-                hi0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[0], hi0, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bt[0], lo0, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bt[1], lo0, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[1], lo0, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bt[0], lo0, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) af[pl] = an[pl];
         }
+        // every fragment of A(p) is in registers (the tail group's in `af`): the image may be overwritten, A(p + 1) has landed
+        phase_barrier();  // B(p)
+        if (!(DAD3D_SPLIT_ABLATE & 16) && p + 1 < NP) read_frags(p + 1, gbase, an);
+        if (FIRST) planes(rawt[0], rawt[1], bt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!((DAD3D_SPLIT_ABLATE & 4) && !FIRST)) {  // the tail group, column block c0 only
+            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[2], lo0, 0, 0, 0);
+            hi0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[0], hi0, 0, 0, 0);
+            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bt[0], lo0, 0, 0, 0);
+            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bt[1], lo0, 0, 0, 0);
+            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[1], lo0, 0, 0, 0);
+            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bt[0], lo0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // accumulators -> partial tile kh [image][column], small + large; D layout: row = (lane >> 4) * 4 + reg, column = lane & 15
         float* ot = ot0 + (p & 1) * (2 * QB * OS);
+        if (!(DAD3D_SPLIT_ABLATE & 8)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c0] = lo0[r] + hi0[r], ot[r * OS + 16 * c1] = lo1[r] + hi1[r];
+            for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c1] = lo1[r] + hi1[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c0] = lo0[r] + hi0[r];
+        } else if (lo0[0] + hi0[0] + lo1[0] + hi1[0] == 123.456f) ot[0] = 0.f;
+        if ((DAD3D_SPLIT_ABLATE & 16) && p + 1 < NP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            read_frags(p + 1, gbase, an);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[pl] = an[pl];
     };
 
     phase_barrier();  // S0
-    gemm(0, std::true_type{});
-    phase_barrier();  // P(0)
+    read_frags(0, gbase, af);
+    phase(0, std::true_type{});
 #pragma unroll 1
-    for (int p = 1; p < NP; ++p) {
-        gemm(p, std::false_type{});
-        phase_barrier();  // P(p)
-    }
+    for (int p = 1; p < NP; ++p) phase(p, std::false_type{});
+    phase_barrier();  // E
 }
 
 size_t flame_decode_split_lds_bytes() { return (size_t)Lds::total; }

@@ -42,22 +42,85 @@ struct EpiCtx {  // uniform over the workgroup
 // v_posed of the vertex; W, w2 = sum of the five skinning weights, the jaw's; lh, ln = first landmark slot of the vertex, the slot
 // chained after it; st3 / stp / stl = store the 3-D vertex / the projection / landmarks (image inside the batch, vertex inside the
 // mesh, output given); vrow = b * V + (a vertex of the tile): the stores go to vertex vrow + VOFF; bnl = b * n_lmk.
+// The same (vertex, image) in two steps for callers that interleave several of them (flame_decode_split.hip's finisher waves): the
+// arithmetic with SCALAR fused multiply-adds -- bit-identical to the packed form below: a v_pk_fma_f32 IS two IEEE fmas -- and the stores.
+// Scalar because beside a partner wave streaming bf16 MFMAs the packed-f32 form returned, now and then, a wrong LOW half in the last
+// sixteen lanes of a finisher's first call behind a barrier: x of a rotated vertex computed with another row of R while y, z and the
+// constants' registers were right (profiles/r06_kernel_log.md section 4).
+struct VertexOut {
+    float rx, ry, rz, ox, oy, oz;  // 3-D vertex | projection (oz: 3-component projections only)
+};
+__device__ __forceinline__ VertexOut vertex_math_scalar(const EpiCtx& cx, float4 c0, float4 c1, float4 c2, float4 c3, float4 c4, float4 c5, float jx, float jy, float jz,
+                                                        float ex, float ey, float ez, float W, float w2) {
+    const float sc = c4.z;
+    const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
+    const float qx = __builtin_fmaf(c0.z, dz, __builtin_fmaf(c0.y, dy, c0.x * dx));
+    const float qy = __builtin_fmaf(c1.y, dz, __builtin_fmaf(c1.x, dy, c0.w * dx));
+    const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
+    const float px = __builtin_fmaf(qx, w2, ex * W), py = __builtin_fmaf(qy, w2, ey * W);
+    const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
+    VertexOut o;
+    o.rx = __builtin_fmaf(c2.w, pz, __builtin_fmaf(c2.z, py, c2.y * px));  // flame.py:226-228: R.v with R = [b1 b2 b3]
+    o.ry = __builtin_fmaf(c3.z, pz, __builtin_fmaf(c3.y, py, c3.x * px));
+    o.rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
+    // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+    o.ox = (__builtin_fmaf(o.rx, sc, c4.w) + 1.0f) / 2.0f * cx.image_size;
+    o.oy = (__builtin_fmaf(o.ry, sc, c5.x) + 1.0f) / 2.0f * cx.image_size;
+    o.oz = cx.zsign * ((__builtin_fmaf(o.rz, sc, 0.0f) + 1.0f) / 2.0f * cx.image_size);
+    return o;
+}
 template <bool TO2D, int VOFF>
+__device__ __forceinline__ void vertex_store(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, const VertexOut& o, int lh, int ln, bool st3, bool stp,
+                                             bool stl, unsigned vrow, unsigned bnl) {
+    if (DAD3D_PIPE_ABLATE & 1) {
+        if (o.ox == 12345.678f) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.rx, o.ry, o.rz}), rs3, 0, 0, 0);
+    } else {
+        if (st3)
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.rx, o.ry, o.rz}), rs3, (int)(vrow * 12u), 12 * VOFF, DAD3D_PIPE_STORE_AUX);
+        if (stp) {
+            if (TO2D) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{o.ox, o.oy}), rsp, (int)(vrow * 8u), 8 * VOFF, DAD3D_PIPE_STORE_AUX);
+            else __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.ox, o.oy, o.oz}), rsp, (int)(vrow * 12u), 12 * VOFF, DAD3D_PIPE_STORE_AUX);
+        }
+    }
+    if (stl) {
+        auto put = [&](int slot) {
+            const unsigned off = (bnl + (unsigned)slot) * 8u;
+            if (cx.lx) *reinterpret_cast<f2u*>(cx.lx + off) = f2u{o.ox, o.oy};
+            if (cx.lp) *reinterpret_cast<i2u*>(cx.lp + off) = i2u{(int)o.ox, (int)o.oy};  // numpy .astype(int): toward zero
+        };
+        put(lh);
+        if (ln >= 0) {  // duplicate indices in the landmark list: the chain goes on
+            put(ln);
+            for (int slot = cx.lmk_next[ln]; slot >= 0; slot = cx.lmk_next[slot]) put(slot);
+        }
+    }
+}
+
+// PACKED = false: vertex_math_scalar + vertex_store above.
+template <bool TO2D, int VOFF, bool PACKED = true>
 __device__ __forceinline__ void finish_vertex(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, float4 c0, float4 c1, float4 c2, float4 c3, float4 c4, float4 c5, float jx, float jy, float jz, float ex, float ey, float ez,
                                               float W, float w2, int lh, int ln, bool st3, bool stp, bool stl, unsigned vrow, unsigned bnl) {
+    if constexpr (!PACKED) {
+        vertex_store<TO2D, VOFF>(cx, rs3, rsp, vertex_math_scalar(cx, c0, c1, c2, c3, c4, c5, jx, jy, jz, ex, ey, ez, W, w2), lh, ln, st3, stp, stl, vrow, bnl);
+        return;
+    }
     const float sc = c4.z;
     // smplx lbs steps 5-6 with only the jaw rotating: T.[v;1] = W v + w_jaw (R_jaw - I)(v - J_jaw)
     const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
-    const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
-    const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
-    const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
-    const float px = pxy.x, py = pxy.y;
-    const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
-    // flame.py:226-228: R.v with R = [b1 b2 b3]
-    const f32x2 rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
-    const float rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
-    // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
-    const f32x2 oxy = (fma2(rxy, sc, f32x2{c4.w, c5.x}) + 1.0f) / 2.0f * cx.image_size;
+    f32x2 rxy, oxy;
+    float rz;
+    {
+        const f32x2 qxy = fma2(f32x2{c0.z, c1.y}, dz, fma2(f32x2{c0.y, c1.x}, dy, f32x2{c0.x, c0.w} * dx));  // rows 0, 1 of D
+        const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
+        const f32x2 pxy = fma2(qxy, w2, f32x2{ex, ey} * W);
+        const float px = pxy.x, py = pxy.y;
+        const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
+        // flame.py:226-228: R.v with R = [b1 b2 b3]
+        rxy = fma2(f32x2{c2.w, c3.z}, pz, fma2(f32x2{c2.z, c3.y}, py, f32x2{c2.y, c3.x} * px));
+        rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
+        // head_mesh.py:39-43: v *= s ; v += t (tz = 0) ; (v + 1) / 2 * image_size
+        oxy = (fma2(rxy, sc, f32x2{c4.w, c5.x}) + 1.0f) / 2.0f * cx.image_size;
+    }
     const float ox = oxy.x, oy = oxy.y;
     // neighbouring lanes = consecutive vertices of one image: contiguous runs per store instruction
     if (DAD3D_PIPE_ABLATE & 1) {

@@ -11,7 +11,7 @@ mkdir -p "$root/tools/_variants"; tmp="$(mktemp -d)"; trap 'rm -rf "$tmp"' EXIT
 (cd "$S" && make -s)
 $H $C $flags -x hip -c "$src" -o "$tmp/fd.o"
 $H $C $flags -x hip -c "${PIPE_SRC:-$S/flame_decode_pipe.hip}" -o "$tmp/fdp.o"  # PIPE_SRC: another revision of the pipelined kernel (e.g. `git show HEAD:...` into a file)
-$H $C $flags -x hip -c "${SPLIT_SRC:-$S/flame_decode_split.hip}" -o "$tmp/fds.o"  # SPLIT_SRC: another revision of the bf16x3 split kernel
+$H $C $flags -fno-slp-vectorize -x hip -c "${SPLIT_SRC:-$S/flame_decode_split.hip}" -o "$tmp/fds.o"  # SPLIT_SRC: another revision of the bf16x3 split kernel
 $H $C $flags -DDAD3D_DIAG_SPIN_ENV -x hip -c "$S/capi.cpp" -o "$tmp/capi.o"
 $H --offload-arch=gfx950 -shared -fPIC -o "$root/tools/_variants/lib_$name.so" "$tmp/fd.o" "$tmp/fdp.o" "$tmp/fds.o" "$tmp/capi.o" "$S/flame_backward.o" "$S/sim3dr_kernels.o" "$S/projection.o" "$S/preprocess.o" "$S/mesh_losses.o" "$S/cnn_glue.o" "$S/sim3dr_compat.o"
 echo "built tools/_variants/lib_$name.so"
