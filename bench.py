@@ -508,6 +508,7 @@ def secondary_decode_b256(hm, lib, lmk_idx, dev, steps: int = 400, settle: int =
            "steps": steps, "settle_passes": settle_passes, "ms_per_step": t * 1e3, "images_per_sec": b / t, "bound": "mfma", "achieved": flops / t / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
            "unit": "TFLOP/s", "frac": flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "algorithmic_bytes_per_launch": alg,
            "hbm_equiv_GBps": alg / t / 1e9, "hbm_frac": alg / t / 1e9 / PEAK_HBM_GBS}
+    g = None
     try:
         g = np.load(os.path.join(ROOT, "tests", "golden", "decode_b256_golden.npz"))
         sub = g["subset"]
@@ -523,6 +524,7 @@ def secondary_decode_b256(hm, lib, lmk_idx, dev, steps: int = 400, settle: int =
     except Exception as e:
         out["verification"] = {"checked": False, "why": f"{type(e).__name__}: {e}"}
         out["outputs_verified"] = None
+    out["split"] = secondary_decode_b256_split(hm, lib, dev, params, g if out["verification"].get("checked") else None, lmk_idx, stream, steps, settle, t)
     # BASELINE configs[3]'s per-GPU work (2048 rows over 8 GPUs = 256 each, only the 445 projected landmarks are gathered): the same rows,
     # landmark outputs only -> the C ABI runs the sub-model of the listed vertices (include/dad3d.h: dad3d_flame_num_landmark_vertices).
     lmk_only = torch.zeros_like(lmk_px)
@@ -560,6 +562,55 @@ def secondary_decode_b256(hm, lib, lmk_idx, dev, steps: int = 400, settle: int =
     f2 = 2.0 * b2 * (3 * n_sub) * 416
     out["landmarks_only"]["b2048"] = {"ms_per_step": t2 * 1e3, "images_per_sec": b2 / t2, "settle_passes": passes_2,
                                       "frac": f2 / t2 / 1e12 / PEAK_FP32_MFMA_TFLOPS, "nonzero": bool(int(lmk2.abs().max()) > 0)}
+    return out
+
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline figure is twice this)
+
+
+def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, steps, settle, t_fp32):
+    """The same configs[2] step on the GATED bf16x3 exact-product split of the contraction (csrc/flame_decode_split.hip,
+    dad3d_flame_select_kernel(DAD3D_KERNEL_SPLIT_BF16)): a pre-pass + the tile kernel per step, both inside the timed launches; outputs
+    held to the same goldens and bars as the fp32 leg. Not the default, not the headline: `value` / `dtype` / `roofline` stay on fp32."""
+    from dad_3dheads_amd import _lib
+
+    b = params.shape[0]
+    twin = hm.fork()
+    twin.flame.select_kernel("split_bf16")
+    p2 = params.clone()
+    verts3d = torch.empty((b, N_VERTS, 3), dtype=torch.float32, device=dev)
+    proj3 = torch.empty((b, N_VERTS, 3), dtype=torch.float32, device=dev)
+    lmk_px = torch.empty((b, N_LMK, 2), dtype=torch.int32, device=dev)
+    call = (twin.flame._handle, p2.data_ptr(), b, _lib.MUTATE_PARAMS, verts3d.data_ptr(), proj3.data_ptr(), None, lmk_px.data_ptr(), stream.cuda_stream)
+
+    def step():
+        st = lib.dad3d_flame_decode(*call)
+        if st:
+            _lib.check(st)
+
+    try:
+        t, passes = events_per_step(step, steps, stream, dev, warmup=50, settle=settle)
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    rows16 = (b + 15) // 16 * 16
+    issued = 6 * 2.0 * rows16 * 416 * 64 * ((N_VERTS + 19) // 20)  # six bf16 MFMA products per (row, k, column) of every 64-column tile
+    flops = FLOP_PER_IMAGE * b
+    out = {"workload": "BASELINE configs[2] on the gated bf16x3 split: the same 256 rows and outputs, pre-pass + tile kernel per step",
+           "kernel": "split_params_kernel + flame_decode_split_kernel<false>", "dtype": "bf16x3 exact-product split, fp32 accumulate",
+           "steps": steps, "settle_passes": passes, "ms_per_step": t * 1e3, "images_per_sec": b / t, "speedup_vs_fp32_leg": t_fp32 / t,
+           "issued_bf16_flop_per_step": issued, "frac_bf16": issued / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+           "fp32_equivalent_TFLOPs": flops / t / 1e12, "fp32_equivalent_frac_of_fp32_mfma_peak": flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+           "error_vs_float64": "profiles/r06_split_error.md (2-3x closer than the fp32 kernel on every line)"}
+    if golden is not None:
+        sub = torch.from_numpy(golden["subset"]).to(dev)
+        dv = float(np.abs(verts3d[:, sub].cpu().numpy() - golden["v3d_sub"]).max())
+        dp = float(np.abs(proj3[:, sub].cpu().numpy() - golden["proj3_sub"]).max())
+        gather_exact = bool(torch.equal(lmk_px, proj3[:, torch.from_numpy(lmk_idx).to(dev), :2].to(torch.int32)))
+        out["verification"] = {"rows": b, "max_abs_3d": dv, "max_abs_px": dp, "landmark_gather_exact": gather_exact,
+                               "tz_zeroed_like_reference": bool((p2[:, 411] == 0).all())}
+        out["outputs_verified"] = bool(dv < 5e-6 and dp < 1e-3 and gather_exact and out["verification"]["tz_zeroed_like_reference"])
+    else:
+        out["outputs_verified"] = None
     return out
 
 
@@ -625,6 +676,40 @@ def secondary_render_b64(hm, static, dev, rank_seed: int, steps: int = 200, cpu_
     leg["timed_images_match_reference_raster"] = cpu.pop("timed_images_match")
     leg["speedup_vs_cpu_baseline_render"] = leg["images_per_sec"] / cpu["value"]
     return leg, cpu
+
+
+def secondary_e2e_b64(model, lmk_idx, dev, batches: int = 20, cpu_images: int = 30):
+    """The north star's literal sentence, reported SEPARATELY from the metric: the drop-in predictor end to end on
+    the GPU -- uint8 frames resident in HBM -> preprocess -> DAD-3DNet (network.py declaration, random weights, PyTorch-ROCm bf16
+    channels-last) -> re-adjust -> fused decode + 445 landmarks, batches of 64, no host copy in between -- against the reference CPU
+    predictor's call sequence in the same process (predictor.py:97-145: fp32, one 256 x 256 image per call, torch.set_num_threads(8)).
+    MIOpen is NOT tuned here (tuning takes minutes; tools/bench_e2e.py does it: +36 % on the CNN), so the GPU figure is the lower one."""
+    from dad_3dheads_amd.predictor import FaceMeshPredictor
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    from cpu_predictor import cpu_reference_predictor  # imports the oracle: the CPU comparator, never the product
+
+    t_start = time.perf_counter()
+    pred = FaceMeshPredictor.random_init(dtype=torch.bfloat16, tune=False, cuda_id=dev.index or 0, flame_model=model, landmarks=lmk_idx)
+    g = torch.Generator().manual_seed(0)
+    images = torch.randint(0, 255, (BATCH, 256, 256, 3), dtype=torch.uint8, generator=g).to(dev)
+    for _ in range(3):
+        out = pred.predict_tensor(images)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        out = pred.predict_tensor(images)
+    torch.cuda.synchronize(dev)
+    t_gpu = (time.perf_counter() - t0) / batches
+    finite = all(bool(torch.isfinite(v.float()).all()) for v in out.values() if isinstance(v, torch.Tensor))
+    cpu = cpu_reference_predictor(model, lmk_idx, cpu_images, threads=(8,), budget_s=25.0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    gpu_ips = BATCH / t_gpu
+    return {"workload": "FaceMeshPredictor end to end, batch 64 of 256 x 256 uint8 frames resident in HBM (bf16 CNN, random weights) vs the "
+                        "reference CPU predictor's call sequence, one image per call (reported separately from the metric: BASELINE.md 3.7)",
+            "gpu_images_per_sec": gpu_ips, "gpu_ms_per_batch": t_gpu * 1e3, "gpu_batches_timed": batches, "gpu_dtype": "bf16 CNN (MIOpen untuned), f32 decode",
+            "gpu_outputs_finite": finite, "cpu_reference_predictor": cpu, "ratio": gpu_ips / cpu["images_per_s"], "north_star_target_ratio": 200,
+            "meets_north_star_sentence": bool(gpu_ips / cpu["images_per_s"] >= 200), "leg_seconds": time.perf_counter() - t_start}
 
 
 def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
@@ -748,6 +833,8 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
     out = {
         "metric": "images/sec (FLAME decode + 445-lmk projection), batch 64 @ 256^2",
         "value": images / elapsed,
+        "value_compute": images / compute_s if compute_s is not None else None,
+        "value_with_gather": images / with_gather_s if with_gather_s is not None else None,
         "unit": "images/sec",
         "n_gpus": world,
         "steps": args.steps,
@@ -766,6 +853,12 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
                                  else "images / compute time (plain N = 1 run: the metric as BASELINE.json defines it; the same collective ran "
                                       "behind the K steps and is reported as ms_per_step_with_gather)") if from_events
                                 else "wall clock (several streams)",
+            "scaling_note": (None if not (have_gather and n_streams == 1 and with_gather_s) else
+                             f"built-in gather share of the timed region: gather_in_region_us / region = {gather_region_us / (with_gather_s * 1e6):.3f} "
+                             f"(K = {args.steps} steps; the share shrinks as K grows). `value_compute` and `value_with_gather` are printed at EVERY N: read a "
+                             "scaling curve on ONE of them, not on `value` across the plain N = 1 line and the process-group lines. "
+                             + ("Unmeasured on N > 1: this is a world of one." if world == 1 else "")),
+            "toolchain": (lib.dad3d_build_info() or b"").decode("utf-8", "replace"),
             "workload": "BASELINE configs[1]: batch=64 synthetic 256x256 per GPU, 445_landmarks path "
                         "(3d_vertices + projected_vertices + 445 int landmarks per image), seeded synthetic "
                         "FLAME-shaped model (real flame.pkl not redistributed)",
@@ -826,7 +919,13 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         render, cpu_render = secondary_render_b64(hm, static, dev, GOLDEN_SEED)
         out["secondary"]["render_b64"] = render
         out["cpu_baseline_render"] = cpu_render
+        try:
+            out["secondary"]["e2e_b64"] = secondary_e2e_b64(model, lmk_idx, dev)
+        except Exception as e:  # the metric's line must not depend on the CNN stack
+            out["secondary"]["e2e_b64"] = {"error": f"{type(e).__name__}: {e}"}
+        out["secondary"]["decode_b256_split"] = out["secondary"]["decode_b256"].pop("split")
         out["secondary"]["outputs_verified"] = bool(out["secondary"]["decode_b256"]["outputs_verified"]) and \
+            bool(out["secondary"]["decode_b256_split"].get("outputs_verified")) and \
             bool(out["secondary"]["decode_b256"]["landmarks_only"]["outputs_verified"]) and \
             bool(render["timed_images_match_reference_raster"]) and bool(out["config"]["outputs_verified"])
     return out

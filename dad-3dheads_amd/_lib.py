@@ -64,6 +64,7 @@ SIGNATURES = {
     "dad3d_last_error": (C.c_char_p, []),
     "dad3d_clear_error": (None, []),
     "dad3d_version": (_I, []),
+    "dad3d_build_info": (C.c_char_p, []),
     "dad3d_device_count": (_I, []),
     "dad3d_flame_create": (_I, [C.POINTER(FlameModelC), C.POINTER(FlameConstsC), _F, _I, C.POINTER(_P)]),
     "dad3d_flame_destroy": (None, [_P]),

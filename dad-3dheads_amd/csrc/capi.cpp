@@ -180,6 +180,18 @@ extern "C" {
 const char* dad3d_last_error(void) { return g_last_error.c_str(); }
 void dad3d_clear_error(void) { g_last_error.clear(); }
 int dad3d_version(void) { return DAD3D_VERSION; }
+const char* dad3d_build_info(void) {
+    static const std::string info = [] {
+        int rt = 0, drv = 0;
+        (void)hipRuntimeGetVersion(&rt);
+        (void)hipDriverGetVersion(&drv);
+        char buf[384];
+        snprintf(buf, sizeof buf, "built: clang %s, HIP headers %d.%d.%d; running: HIP runtime %d, driver %d", __clang_version__, HIP_VERSION_MAJOR,
+                 HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt, drv);
+        return std::string(buf);
+    }();
+    return info.c_str();
+}
 int dad3d_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -38,6 +38,9 @@ typedef enum dad3d_status {
 DAD3D_EXPORT const char* dad3d_last_error(void);
 DAD3D_EXPORT void dad3d_clear_error(void); /* reset the thread-local message to "" */
 DAD3D_EXPORT int dad3d_version(void);
+/* The toolchain pair, for benchmark records: "built: clang <version>, HIP headers a.b.c; running: HIP runtime <n>, driver <n>" -- the
+ * compiler and headers this library was built with (the authoring container) and the runtime it is loaded against (the GPU box). */
+DAD3D_EXPORT const char* dad3d_build_info(void);
 /* Number of visible HIP devices (0 when there is none). Host-only, launches nothing. */
 DAD3D_EXPORT int dad3d_device_count(void);
 

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
-def cpu_reference_predictor(model, lmk_idx, n_images: int):
+def cpu_reference_predictor(model, lmk_idx, n_images: int, threads=None, budget_s: float = 45.0):
     """The reference predictor's call sequence on the host CPU (predictor.py:97-145), one 256 x 256 image per call."""
     import numpy as np
 
@@ -32,14 +32,14 @@ def cpu_reference_predictor(model, lmk_idx, n_images: int):
         return post, pts
 
     tried, counted = {}, {}
-    for threads in sorted({t for t in (1, 8, 32, ncpu) if t <= ncpu}):
+    for threads in sorted({t for t in (threads or (1, 8, 32, ncpu)) if t <= ncpu} or {ncpu}):
         torch.set_num_threads(threads)
         for i in range(2):
             one(frames[i])
         # n_images per setting, but never more than ~45 s of it: torch's default of ALL cores is pathologically slow for one 256 x 256
         # image on a many-core host (bench.py's cpu_baseline found the same for the decode alone), and the run must stay bounded
         n, t0 = 0, time.perf_counter()
-        while n < n_images and (n < 3 or time.perf_counter() - t0 < 45.0):
+        while n < n_images and (n < 3 or time.perf_counter() - t0 < budget_s):
             one(frames[n % len(frames)])
             n += 1
         tried[threads], counted[threads] = n / (time.perf_counter() - t0), n

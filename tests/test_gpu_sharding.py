@@ -194,6 +194,11 @@ def test_bench_plain_and_torchrun_lines_agree_and_two_gpus_are_refused():
         assert d["roofline"]["frac"] > 0.3 and d["unit"] == "images/sec"
         # every line runs the job's one collective behind its K steps and prints both per-step times
         assert d["config"]["gather_via"] is not None and d["ms_per_step_with_gather"] >= d["ms_per_step_compute"] > 0
+        # round 6: both definitions of the job's rate at EVERY N (a scaling curve is read on one of them), the gather's share, the toolchain pair
+        assert d["value_compute"] >= d["value_with_gather"] > 0 and d["value"] in (d["value_compute"], d["value_with_gather"])
+        assert "gather_in_region_us / region" in d["config"]["scaling_note"] and "Unmeasured on N > 1" in d["config"]["scaling_note"]
+        assert d["config"]["toolchain"].startswith("built: clang") and "running: HIP runtime" in d["config"]["toolchain"]
+    assert a["value"] == a["value_compute"] and b["value"] == b["value_with_gather"]
     assert "compute" in a["config"]["value_definition"] and "with_gather" in b["config"]["value_definition"]
     assert abs(a["ms_per_step"] - a["ms_per_step_compute"]) < 1e-9 and abs(b["ms_per_step"] - b["ms_per_step_with_gather"]) < 1e-9
     assert "nccl" in b["config"]["parallelism"] and "no process group" in a["config"]["parallelism"]
@@ -240,6 +245,8 @@ def test_bench_eight_ranks_code_path_on_one_gpu():
             assert d["config"]["outputs_verified"] is True and "not a multi-GPU measurement" in d["config"]["parallelism"]
             assert d["ms_per_step_compute"] > 0 and d["ms_per_step_with_gather"] >= d["ms_per_step_compute"]
             assert "with_gather" in d["config"]["value_definition"]
+            assert d["value"] == d["value_with_gather"] and d["value_compute"] >= d["value_with_gather"] > 0  # both at every N
+            assert "gather_in_region_us / region" in d["config"]["scaling_note"] and d["config"]["toolchain"].startswith("built: clang")
         else:
             assert d["config"]["gather_verified"] is True and d["config"]["images_with_coverage"] == 1.0
 
@@ -265,6 +272,8 @@ def test_bench_two_ranks_code_path_on_one_gpu():
         if workload == "decode":
             assert d["config"]["outputs_verified"] is True and d["config"]["handoff_timeouts"] == 0
             assert "not a multi-GPU measurement" in d["config"]["parallelism"]
+            assert d["value"] == d["value_with_gather"] and d["value_compute"] >= d["value_with_gather"] > 0
+            assert "gather_in_region_us / region" in d["config"]["scaling_note"] and "Unmeasured" not in d["config"]["scaling_note"]
         else:
             assert d["config"]["gather_verified"] is True and d["config"]["images_with_coverage"] == 1.0
         assert d["value"] > 0
@@ -291,6 +300,13 @@ def test_driver_command_carries_the_secondary_legs():
     assert rnd["timed_images_match_reference_raster"] is True and rnd["images_with_coverage"] == 1.0 and rnd["images_per_sec"] > 1e5
     lo = b256["landmarks_only"]
     assert lo["outputs_verified"] is True and lo["sub_model_vertices"] > 400 and lo["images_per_sec"] > 1.5 * b256["images_per_sec"]
+    assert lo["landmark_px_differ_from_whole_mesh_launch"] == 0 and 0 < lo["frac"] < 1 and lo["b2048"]["nonzero"] is True  # one arithmetic
+    sp = d["secondary"]["decode_b256_split"]  # the gated bf16x3 split: same rows, same goldens, its own fractions; never the headline
+    assert sp["outputs_verified"] is True and sp["dtype"].startswith("bf16x3") and 0 < sp["frac_bf16"] < 1 and sp["fp32_equivalent_TFLOPs"] > 0
+    assert d["dtype"] == "f32" and "split" not in d["roofline"]["kernel"]
+    e2e = d["secondary"]["e2e_b64"]  # the north star's sentence, reported separately from the metric
+    assert "error" not in e2e, e2e
+    assert e2e["gpu_outputs_finite"] is True and e2e["cpu_reference_predictor"]["threads"] == 8 and e2e["ratio"] > 0 and e2e["north_star_target_ratio"] == 200
     assert rnd["two_streams"]["images_per_sec"] > 0.9 * rnd["images_per_sec"]  # two batches in flight: never meaningfully slower than one
     assert d["cpu_baseline_render"]["value"] > 0 and d["cpu_baseline_render"]["cores"] == 1
     assert d["secondary"]["outputs_verified"] is True
