@@ -678,23 +678,57 @@ def secondary_render_b64(hm, static, dev, rank_seed: int, steps: int = 200, cpu_
     return leg, cpu
 
 
-def secondary_e2e_b64(model, lmk_idx, dev, batches: int = 20, cpu_images: int = 30):
+class E2EWarmup:
+    """Builds the end-to-end predictor and runs its first batches on a thread of its own WHILE the decode-path CPU baseline runs (the GPU
+    is idle then): a fresh box compiles / loads ~200 MIOpen kernels on the CNN's first call (~45 s), and the driver's whole run has to
+    stay inside its budget. Joined before any GPU-timed secondary leg starts."""
+
+    def __init__(self, model, lmk_idx, dev):
+        import threading
+
+        self.pred = self.images = self.error = None
+        self.seconds = 0.0
+
+        def work():
+            t0 = time.perf_counter()
+            try:
+                from dad_3dheads_amd.predictor import FaceMeshPredictor
+
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(torch.cuda.Stream(dev)):
+                    pred = FaceMeshPredictor.random_init(dtype=torch.bfloat16, tune=False, cuda_id=dev.index or 0, flame_model=model, landmarks=lmk_idx)
+                    g = torch.Generator().manual_seed(0)
+                    images = torch.randint(0, 255, (BATCH, 256, 256, 3), dtype=torch.uint8, generator=g).to(dev)
+                    for _ in range(3):
+                        pred.predict_tensor(images)
+                    torch.cuda.current_stream(dev).synchronize()
+                self.pred, self.images = pred, images
+            except Exception as e:  # reported in the leg, never fatal for the metric's line
+                self.error = f"{type(e).__name__}: {e}"
+            self.seconds = time.perf_counter() - t0
+
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def join(self):
+        self.thread.join()
+        return self
+
+
+def secondary_e2e_b64(warm, model, lmk_idx, dev, batches: int = 20, cpu_images: int = 30):
     """The north star's literal sentence, reported SEPARATELY from the metric: the drop-in predictor end to end on
     the GPU -- uint8 frames resident in HBM -> preprocess -> DAD-3DNet (network.py declaration, random weights, PyTorch-ROCm bf16
     channels-last) -> re-adjust -> fused decode + 445 landmarks, batches of 64, no host copy in between -- against the reference CPU
     predictor's call sequence in the same process (predictor.py:97-145: fp32, one 256 x 256 image per call, torch.set_num_threads(8)).
     MIOpen is NOT tuned here (tuning takes minutes; tools/bench_e2e.py does it: +36 % on the CNN), so the GPU figure is the lower one."""
-    from dad_3dheads_amd.predictor import FaceMeshPredictor
-
     sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
     from cpu_predictor import cpu_reference_predictor  # imports the oracle: the CPU comparator, never the product
 
+    if warm.error:
+        return {"error": warm.error}
     t_start = time.perf_counter()
-    pred = FaceMeshPredictor.random_init(dtype=torch.bfloat16, tune=False, cuda_id=dev.index or 0, flame_model=model, landmarks=lmk_idx)
-    g = torch.Generator().manual_seed(0)
-    images = torch.randint(0, 255, (BATCH, 256, 256, 3), dtype=torch.uint8, generator=g).to(dev)
-    for _ in range(3):
-        out = pred.predict_tensor(images)
+    pred, images = warm.pred, warm.images
+    out = pred.predict_tensor(images)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(batches):
@@ -709,7 +743,8 @@ def secondary_e2e_b64(model, lmk_idx, dev, batches: int = 20, cpu_images: int = 
                         "reference CPU predictor's call sequence, one image per call (reported separately from the metric: BASELINE.md 3.7)",
             "gpu_images_per_sec": gpu_ips, "gpu_ms_per_batch": t_gpu * 1e3, "gpu_batches_timed": batches, "gpu_dtype": "bf16 CNN (MIOpen untuned), f32 decode",
             "gpu_outputs_finite": finite, "cpu_reference_predictor": cpu, "ratio": gpu_ips / cpu["images_per_s"], "north_star_target_ratio": 200,
-            "meets_north_star_sentence": bool(gpu_ips / cpu["images_per_s"] >= 200), "leg_seconds": time.perf_counter() - t_start}
+            "meets_north_star_sentence": bool(gpu_ips / cpu["images_per_s"] >= 200), "leg_seconds": time.perf_counter() - t_start,
+            "warmup_seconds_overlapped_with_cpu_baseline": warm.seconds}
 
 
 def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
@@ -907,9 +942,12 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
             "hbm_frac": alg_bytes / kern_s / 1e9 / PEAK_HBM_GBS,
         },
     }
+    e2e_warm = E2EWarmup(model, lmk_idx, dev) if secondary_on else None  # (after every timed decode region; the GPU idles during the next leg)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, lmk_idx)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if e2e_warm is not None:
+        e2e_warm.join()
     if secondary_on:
         out["long_region"] = {"steps": 2000, "ms_per_step": long_s * 1e3, "images_per_sec": BATCH / long_s,
                               "frac": flops / long_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -920,7 +958,7 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         out["secondary"]["render_b64"] = render
         out["cpu_baseline_render"] = cpu_render
         try:
-            out["secondary"]["e2e_b64"] = secondary_e2e_b64(model, lmk_idx, dev)
+            out["secondary"]["e2e_b64"] = secondary_e2e_b64(e2e_warm, model, lmk_idx, dev)
         except Exception as e:  # the metric's line must not depend on the CNN stack
             out["secondary"]["e2e_b64"] = {"error": f"{type(e).__name__}: {e}"}
         out["secondary"]["decode_b256_split"] = out["secondary"]["decode_b256"].pop("split")

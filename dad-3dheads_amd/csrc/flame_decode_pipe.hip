@@ -151,6 +151,10 @@ __global__ __launch_bounds__(512, 2) void flame_decode_pipe_kernel(PipeArgs a) {
     float* cst = smem + Lds::c_off;
     lds_int* parts = (lds_int*)(smem + Lds::y_off);
 
+    // (`wave` stays a per-lane value on purpose. The compiler cannot prove it uniform, so the role split below is an exec-mask branch and
+    // its saved mask is this kernel's "2 SGPR spills": one v_writelane pair at the top, one v_readlane pair at the very end, once per
+    // launch, no scratch. Made uniform with readfirstlane the branch turns scalar -- and 30-odd values turn into SGPRs with it: 7 spills
+    // inside the loops instead of 2 outside them. tests/test_kernel_resources.py holds the line: scratch 0, VGPR spills 0.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_id = blockIdx.x;
     if (CHUNKED) {
