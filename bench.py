@@ -148,7 +148,7 @@ def pmc_json(name, key):
     collected in separate runs, KB units, FETCH doubled per MI355X_MICROARCH.md; SQ_VALU_MFMA_BUSY_CYCLES). PMC cannot be
     collected inside this process: these are CONSTANTS READ FROM COMMITTED FILES (the file is named next to them), null when
     absent."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")) as f:
                 return json.load(f)[key], f"profiles/{rnd}_{name}.json"
