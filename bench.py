@@ -31,13 +31,18 @@ collective behind its K steps and prints two per-step times from device events o
 `ms_per_step_compute` ([first launch ... last launch]) and `ms_per_step_with_gather` ([first launch ... end of the all-gather]).
 `value` is images / the COMPUTE time for the plain N = 1 run (the metric as BASELINE.json defines it: decode + landmark
 projection; there is nobody to gather from) and images / the time WITH the gather under a process group (any N, N = 1 under
-torchrun included); `config.value_definition` says which. Rank 0 prints ONE JSON line.
+torchrun included); `config.value_definition` says which, and BOTH rates are printed at every N as `value_compute` / `value_with_gather` with the
+gather's built-in share of the region in `config.scaling_note` -- read a scaling curve on one of them. `config.toolchain` = the compiler / HIP headers
+the library was built with and the runtime it runs on. Rank 0 prints ONE JSON line.
 
 Secondary legs (plain N = 1 decode run only, AFTER the contract region, none of them touches `value` / `ms_per_step` / `roofline`;
 `--no-secondary` skips them): `long_region` = 2000 more launches of the same step between two hipEvents (the driver's K = 20 region
 is 0.26 ms -- too short to mean much on its own); `secondary.decode_b256` = BASELINE configs[2] (batch 256, head_mesh path:
 3d_vertices + 3-component projection + landmarks, 125 764 B per image) with its own MFMA / HBM fractions, every row checked against
-reference-HeadMesh goldens; `secondary.render_b64` = BASELINE configs[4]'s per-GPU share (decode -> normals + Phong -> raster, three
+reference-HeadMesh goldens, with `landmarks_only` (configs[3]'s per-GPU share and all 2048 rows: bit-equal to the whole-mesh launch);
+`secondary.decode_b256_split` = the same configs[2] step on the GATED bf16x3 exact-product split (its own fractions against the bf16 peak; never the
+headline); `secondary.e2e_b64` = the drop-in predictor end to end against the reference CPU predictor's call sequence in the same process (the north
+star's 200x sentence; reported separately from the metric); `secondary.render_b64` = BASELINE configs[4]'s per-GPU share (decode -> normals + Phong -> raster, three
 launches per batch of 64) with the timed images checked against the reference rasteriser, and `cpu_baseline_render` beside it.
 
 `--workload render` (BASELINE configs[4], not the headline metric): per step and GPU 64 images of head_mesh decode ->
