@@ -94,9 +94,11 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
     char* blk = a.aplanes + (size_t)(b / QB) * BLK;
     char* row = blk + (size_t)(b % QB) * RS;
     // [400,403) jaw | [403,409) 6-DoF rotation | [409,412) translation | [412] scale   (FlameParams.from_3dmm, flame.py:48-73)
-    const float jaw[3] = {prow[kNumBeta], prow[kNumBeta + 1], prow[kNumBeta + 2]};
-    float D[9];
-    rodrigues_minus_identity_lean(jaw, D);  // pose feature of the jaw (smplx lbs step 3) = R_jaw - I; the fp32 kernel's code
+    float D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t >= 192) {  // the last wave only: it holds the pairs of the row's tail and the constants' thread (the other three go straight to the betas)
+        const float jaw[3] = {prow[kNumBeta], prow[kNumBeta + 1], prow[kNumBeta + 2]};
+        rodrigues_minus_identity_lean(jaw, D);  // pose feature of the jaw (smplx lbs step 3) = R_jaw - I; the fp32 kernel's code
+    }
     if (t < 208) {
         // elements k0 = 2 t, k0 + 1 of the A row: betas | pose feature (9) | the template's 1 | zero padding
         const int k0 = 2 * t;
