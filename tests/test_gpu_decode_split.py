@@ -219,3 +219,28 @@ def test_split_kernel_refuses_what_it_does_not_cover_and_replays_from_a_graph(me
     twin.flame.select_kernel("split_bf16")
     other = twin.decode(p.clone(), to_2d=True, landmarks=True)
     assert torch.equal(other["proj"], want["proj"])
+
+
+def test_split_kernel_two_forks_on_two_streams(meshes):
+    """Two batches in flight on one GPU (bench.py --streams 2 in split mode): each fork owns its scratch (planes + constants), the basis is
+    shared; launches interleaved on two streams return what one stream returns."""
+    split, _ = meshes
+    twin = split.fork()
+    twin.flame.select_kernel("split_bf16")
+    pa = torch.from_numpy(synthetic.synthetic_params(200, seed=6600)).cuda()
+    pb = torch.from_numpy(synthetic.synthetic_params(136, seed=6601)).cuda()
+    want_a = split.decode(pa.clone(), to_2d=True, landmarks=True)
+    want_b = split.decode(pb.clone(), to_2d=True, landmarks=True)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            oa = split.decode(pa.clone(), to_2d=True, landmarks=True)
+        with torch.cuda.stream(sb):
+            ob = twin.decode(pb.clone(), to_2d=True, landmarks=True)
+        outs.append((oa, ob))
+    sa.synchronize(), sb.synchronize()
+    for oa, ob in outs:
+        for k in ("verts3d", "proj", "lmk_xy"):
+            assert torch.equal(oa[k], want_a[k]) and torch.equal(ob[k], want_b[k]), k
