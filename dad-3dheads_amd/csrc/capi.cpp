@@ -436,6 +436,13 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
             return st2;
         }
     }
+    // the device-to-device copies above are ordered on the NULL stream and may return before they ran: a first launch of the fork on a
+    // non-blocking stream must not overtake them
+    if (hipStreamSynchronize(nullptr) != hipSuccess) {
+        set_error("dad3d_flame_fork: hipStreamSynchronize failed");
+        dad3d_flame_destroy(h.release());
+        return DAD3D_E_HIP;
+    }
     *out = h.release();
     return DAD3D_OK;
 }
@@ -660,7 +667,9 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
             (void)hipFree(h->d_split_a);
             h->d_split_a = nullptr, h->split_cap = 0;
             DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitBlockBytes));
-            DAD3D_HIP_TRY(hipMemset(h->d_split_a, 0, (size_t)n_phase * kSplitBlockBytes));  // (the padding is copied into LDS, never read)
+            // (the padding is copied into LDS, never read.) On the LAUNCH's stream: hipMemset is ordered on the null stream only, and a
+            // non-blocking stream's pre-pass overtook it -- zero planes under the first launch of a fork (found by the two-streams test)
+            DAD3D_HIP_TRY(hipMemsetAsync(h->d_split_a, 0, (size_t)n_phase * kSplitBlockBytes, s));
             h->split_cap = n_phase;
         }
         SplitArgs sa{};

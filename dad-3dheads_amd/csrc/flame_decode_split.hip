@@ -36,8 +36,12 @@
 #include "flame_pipe_epilogue.hpp"
 
 #ifndef DAD3D_SPLIT_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no finishing, 2 = no staging after the second phase,
-#define DAD3D_SPLIT_ABLATE 0  // 4 = no MFMAs, 8 = no parking, 16 = no fragment prefetch behind the barrier. Results wrong, timing
-#endif                        // meaningful. 0 in the product
+#define DAD3D_SPLIT_ABLATE 0  // 4 = no MFMAs, 8 = no parking, 16 = no fragment prefetch behind the barrier, 256 = no stores,
+#endif                        // 512 = no finishing arithmetic. Results wrong, timing meaningful. 0 in the product
+
+#ifndef DAD3D_SPLIT_FIN_PRIO
+#define DAD3D_SPLIT_FIN_PRIO 1
+#endif
 
 namespace dad3d {
 
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
     char* blk = a.aplanes + (size_t)(b / QB) * BLK;
     char* row = blk + (size_t)(b % QB) * RS;
     // [400,403) jaw | [403,409) 6-DoF rotation | [409,412) translation | [412] scale   (FlameParams.from_3dmm, flame.py:48-73)
+    // constants of an image (24 floats): D = R_jaw - I (9) | G = 6-DoF rotation (9) | s h | (tx + 1) h | (ty + 1) h | h
     float D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (t >= 192) {  // the last wave only: it holds the pairs of the row's tail and the constants' thread (the other three go straight to the betas)
         const float jaw[3] = {prow[kNumBeta], prow[kNumBeta + 1], prow[kNumBeta + 2]};
@@ -134,8 +139,10 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
         c[1] = float4{D[4], D[5], D[6], D[7]};
         c[2] = float4{D[8], G[0], G[1], G[2]};
         c[3] = float4{G[3], G[4], G[5], G[6]};
-        c[4] = float4{G[7], G[8], s, prow[409]};
-        c[5] = float4{prow[410], 0.f, 0.f, 0.f};
+        // head_mesh.py:39-43 ((v s + t) + 1) / 2 * image_size as ONE fma per component in the finishers: v (s h) + (t + 1) h, h = image_size / 2
+        const float hh = a.image_size * 0.5f;
+        c[4] = float4{G[7], G[8], s * hh, (prow[409] + 1.0f) * hh};
+        c[5] = float4{(prow[410] + 1.0f) * hh, hh, 0.f, 0.f};
         if ((a.flags & DAD3D_MUTATE_PARAMS) && live) prow[kNumBeta + 11] = 0.0f;  // translation z := 0 (head_mesh.py:41)
     }
 }
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
 //   S0      A(0) and its constants are in LDS (and the tile's rows of the vertex table)
 //   B(p)    mma waves: every fragment of A(p) has been READ (its last six MFMAs and the parking of tile p follow the barrier);
 //           stager: A(p + 1) and its constants have LANDED (A(p + 2) is in flight); finishers: tile p - 2 has been consumed
-//   E       tile n_phase - 1 is parked
+//   E       tile n_phase - 1 is parked (in the window in front of it and behind it -- the drain -- mma waves 0 and 1 finish too)
 // mma waves, window p + 1: first fragments of A(p + 1) requested, tail MFMAs of phase p, tile p parked in tile pair p & 1, slots 0..5 of
 // phase p + 1. Stager, window p: requests the planes of phase p + 2 into image (p + 2) % 3 -- last read in front of B(p - 1) -- and its
 // constants into ring slot (p + 2) & 7, then waits for phase p + 1's (requested a window earlier: a global -> LDS round trip is as
@@ -214,72 +221,106 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
         phase_barrier();  // E
         return;
     }
+    // ============================== finishing: the finisher waves, and mma waves 0 and 1 in the two drain windows ======================
+    // The 320 (image, vertex) pairs of a phase as five wave-wide calls, pair = 64 call + lane -> image pair / 20, vertex pair % 20:
+    // neighbouring lanes = consecutive vertices of one image (runs of 240 / 160 contiguous bytes per store instruction). One call = 64
+    // pairs: operands of a pair (all from LDS), its arithmetic, its stores: ~45 FP instructions. Finisher wave j owns calls j and j + 3
+    // of EVERY phase (a barrier window costs its busiest wave's two calls however they rotate), so everything about a call that does
+    // not depend on the phase -- image and vertex of the lane, its row of the vertex table, LDS and output offsets: a dozen integer
+    // instructions, half of them quarter-rate multiplies -- is computed once per launch (Geo). A wave's two calls of a window are
+    // written out side by side -- loads of both, arithmetic of both, stores of both -- so that the second one's LDS round trips and
+    // dependent chains hide behind the first one's (one call alone is ~1.4 k cycles beside the MFMA stream, mostly latency).
+    const unsigned nl = (unsigned)a.n_lmk;
+    EpiCtx cx;
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.verts3d), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.proj), 0, 0x7fffffff, 0x00020000);
+    cx.lx = reinterpret_cast<char*>(a.lmk_xy), cx.lp = reinterpret_cast<char*>(a.lmk_px);
+    cx.lmk_next = a.lmk_next;
+    cx.image_size = a.image_size;
+    cx.zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
+    constexpr unsigned kPB = TO2D ? 8u : 12u;  // bytes of a projected vertex
+    struct Geo {       // of (call, lane), the same in every phase
+        float4 vt;     // skinning weights W, w2 | landmark slot head, next
+        int i;         // image of the phase
+        int cp_off;    // byte offset of its constants inside a ring slot
+        int ot_off;    // float offset of the pair's accumulators inside a partial tile; the jaw joint's: jt_off
+        int jt_off;
+        unsigned off3, offp;  // byte offsets of the vertex in verts3d / proj for image i of phase 0
+        bool vlive;
+    };
+    auto make_geo = [&](int c) {  // behind S0: reads the vertex table's rows from LDS
+        Geo g;
+        const int pair = 64 * c + lane, u = pair - TV * (pair / TV);
+        g.i = pair / TV;
+        g.vt = vt_lds[u];
+        g.cp_off = g.i * 96;
+        g.ot_off = g.i * OS + 3 * u, g.jt_off = g.i * OS + kJawCol;
+        const unsigned vrow = (unsigned)g.i * (unsigned)a.n_verts + (unsigned)(v0 + u);
+        g.off3 = vrow * 12u, g.offp = vrow * kPB;
+        g.vlive = v0 + u < a.n_verts;
+        return g;
+    };
+    static_assert(kPairs == 5 * 64, "five wave-wide calls per phase: finisher j takes j and j + 3");
+    struct Call {
+        float4 k0, k1, k2, k3, k4, k5;
+        float j0[3], j1[3], e0[3], e1[3];  // jaw joint and v_posed of the pair: partial sums of the two K halves
+    };
+    auto load_call = [&](int q, const Geo& g, Call& t) {
+        const float4* cp = reinterpret_cast<const float4*>(cring + (q & 7) * CST + g.cp_off);
+        t.k0 = cp[0], t.k1 = cp[1], t.k2 = cp[2], t.k3 = cp[3], t.k4 = cp[4], t.k5 = cp[5];
+        const float* ot = otile + (q & 1) * (2 * QB * OS);  // partial tile of K half 0; half 1 is QB * OS floats on
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t.j0[k] = ot[g.jt_off + k], t.j1[k] = ot[QB * OS + g.jt_off + k];  // J_jaw of this image, from the GEMM
+            t.e0[k] = ot[g.ot_off + k], t.e1[k] = ot[QB * OS + g.ot_off + k];
+        }
+    };
+    auto math_call = [&](const Geo& g, const Call& t) {
+        if (DAD3D_SPLIT_ABLATE & 512) return VertexOut{t.e0[0] + t.k0.x, t.e0[1] + t.k1.x, t.e0[2] + t.k2.x, t.e1[0] + t.k3.x + t.j0[0], t.e1[1] + t.k4.x + t.j0[1], t.e1[2] + t.k5.x + t.j1[0]};
+        return vertex_math_folded(cx, t.k0, t.k1, t.k2, t.k3, t.k4, t.k5, t.j0[0] + t.j1[0], t.j0[1] + t.j1[1], t.j0[2] + t.j1[2], t.e0[0] + t.e1[0],
+                                  t.e0[1] + t.e1[1], t.e0[2] + t.e1[2], g.vt.x, g.vt.y);
+    };
+    auto store_call = [&](int q, const Geo& g, const VertexOut& o) {
+        const int b = q * QB + g.i;
+        const bool live = b < B && g.vlive && !((DAD3D_SPLIT_ABLATE & 256) && o.ox != 12345.678f);
+        const unsigned row0 = (unsigned)(q * QB) * (unsigned)a.n_verts;  // (scalar)
+        vertex_store_at<TO2D>(cx, rs3, rsp, o, __float_as_int(g.vt.z), __float_as_int(g.vt.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
+                              live && nl > 0 && __float_as_int(g.vt.z) >= 0, g.off3 + row0 * 12u, g.offp + row0 * kPB, (unsigned)b * nl);
+    };
+    auto finish_one = [&](int q, const Geo& g) {
+        Call t;
+        load_call(q, g, t);
+        store_call(q, g, math_call(g, t));
+    };
+    auto finish_two = [&](int q, const Geo& ga, const Geo& gb) {
+        Call ta, tb;
+        load_call(q, ga, ta);
+        load_call(q, gb, tb);
+        const VertexOut oa = math_call(ga, ta), ob = math_call(gb, tb);
+        store_call(q, ga, oa);
+        store_call(q, gb, ob);
+    };
+
     if (wave > 4) {
         // ===================================================== finisher waves =========================================================
         const int fj = wave - 5;
-        const unsigned nl = (unsigned)a.n_lmk;
-        EpiCtx cx;
-        const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.verts3d), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.proj), 0, 0x7fffffff, 0x00020000);
-        cx.lx = reinterpret_cast<char*>(a.lmk_xy), cx.lp = reinterpret_cast<char*>(a.lmk_px);
-        cx.lmk_next = a.lmk_next;
-        cx.image_size = a.image_size;
-        cx.zsign = (a.flags & DAD3D_FLIP_Z) ? -1.0f : 1.0f;
-        // The 320 (image, vertex) pairs of a phase as five wave-wide calls, pair = 64 call + lane -> image pair / 20, vertex pair % 20:
-        // neighbouring lanes = consecutive vertices of one image (runs of 240 / 160 contiguous bytes per store instruction). The calls of
-        // phase q go to the three waves in turn, starting one wave further every phase: 2, 2, 1 calls, five per wave over three phases.
-        // One call = 64 pairs: operands of a pair (all from LDS), its arithmetic, its stores. A wave's two calls of a window are
-        // written out side by side -- loads of both, arithmetic of both, stores of both -- so that the second one's LDS round trips and
-        // dependent chains hide behind the first one's (one call alone is ~1.4 k cycles beside the MFMA stream, mostly latency).
-        struct Call {
-            float4 k0, k1, k2, k3, k4, k5, vt;
-            float j0[3], j1[3], e0[3], e1[3];  // jaw joint and v_posed of the pair: partial sums of the two K halves
-            int b, u;
-        };
-        auto load_call = [&](int q, int c, Call& t) {
-            const int pair = 64 * c + lane, i = pair / TV;
-            t.u = pair - TV * i, t.b = q * QB + i;
-            const float4* cp = reinterpret_cast<const float4*>(cring + (q & 7) * CST + i * 96);
-            t.k0 = cp[0], t.k1 = cp[1], t.k2 = cp[2], t.k3 = cp[3], t.k4 = cp[4], t.k5 = cp[5];
-            t.vt = vt_lds[t.u];
-            const float* ot = otile + (q & 1) * (2 * QB * OS) + i * OS;  // partial tile of K half 0; half 1 is QB * OS floats on
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                t.j0[k] = ot[kJawCol + k], t.j1[k] = ot[QB * OS + kJawCol + k];  // J_jaw of this image, from the GEMM
-                t.e0[k] = ot[3 * t.u + k], t.e1[k] = ot[QB * OS + 3 * t.u + k];
-            }
-        };
-        auto math_call = [&](const Call& t) {
-            return vertex_math_scalar(cx, t.k0, t.k1, t.k2, t.k3, t.k4, t.k5, t.j0[0] + t.j1[0], t.j0[1] + t.j1[1], t.j0[2] + t.j1[2], t.e0[0] + t.e1[0],
-                                      t.e0[1] + t.e1[1], t.e0[2] + t.e1[2], t.vt.x, t.vt.y);
-        };
-        auto store_call = [&](const Call& t, const VertexOut& o) {
-            const bool live = t.b < B && v0 + t.u < a.n_verts;
-            vertex_store<TO2D, 0>(cx, rs3, rsp, o, __float_as_int(t.vt.z), __float_as_int(t.vt.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
-                                  live && nl > 0 && __float_as_int(t.vt.z) >= 0, (unsigned)t.b * (unsigned)a.n_verts + (unsigned)(v0 + t.u), (unsigned)t.b * nl);
-        };
-        auto finish = [&](int q) {
-            const int c0 = (fj + 3 - q % 3) % 3;  // calls c0 and c0 + 3 (the latter exists for c0 < 2)
-            Call ta, tb;
-            load_call(q, c0, ta);
-            if (c0 + 3 < kPairs / 64) {
-                load_call(q, c0 + 3, tb);
-                const VertexOut oa = math_call(ta), ob = math_call(tb);
-                store_call(ta, oa);
-                store_call(tb, ob);
-            } else {
-                store_call(ta, math_call(ta));
-            }
-        };
+        // issue priority over the mma wave of the same SIMD: the MFMA chain has slack, the finishers' instructions are the window's bound
+        // (measured 1-2 % of a launch at 1024 / 2048 images, priorities 1 and 3 alike)
+        __builtin_amdgcn_s_setprio(DAD3D_SPLIT_FIN_PRIO);
         phase_barrier();  // S0
+        const Geo ga = make_geo(fj), gb = make_geo(fj < 2 ? fj + 3 : fj);
 #pragma unroll 1
         for (int p = 0; p < NP; ++p) {
-            if (p >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) finish(p - 2);
+            if (p >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) {
+                if (fj < 2) finish_two(p - 2, ga, gb);
+                else finish_one(p - 2, ga);
+            }
             phase_barrier();  // B(p)
         }
-        if (NP >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) finish(NP - 2);
+        // the drain: mma waves 0 and 1 take calls 3 and 4 of the last two tiles (one call per wave and window instead of two)
+        if (NP >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) finish_one(NP - 2, ga);
         phase_barrier();  // E
-        if (!(DAD3D_SPLIT_ABLATE & 1)) finish(NP - 1);
+        if (!(DAD3D_SPLIT_ABLATE & 1)) finish_one(NP - 1, ga);
         return;
     }
 
@@ -386,6 +427,14 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
     phase(0, std::true_type{});
 #pragma unroll 1
     for (int p = 1; p < NP; ++p) phase(p, std::false_type{});
+    // the drain: this wave's share of the last two tiles (the basis registers are dead). Tile NP - 2 has been visible since B(NP - 1)
+    if (wave < 2 && !(DAD3D_SPLIT_ABLATE & 1)) {
+        const Geo g = make_geo(3 + wave);
+        if (NP >= 2) finish_one(NP - 2, g);
+        phase_barrier();  // E
+        finish_one(NP - 1, g);
+        return;
+    }
     phase_barrier();  // E
 }
 

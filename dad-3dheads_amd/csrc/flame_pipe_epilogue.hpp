@@ -69,6 +69,26 @@ __device__ __forceinline__ VertexOut vertex_math_scalar(const EpiCtx& cx, float4
     o.oz = cx.zsign * ((__builtin_fmaf(o.rz, sc, 0.0f) + 1.0f) / 2.0f * cx.image_size);
     return o;
 }
+// The same with the projection folded into the image's constants (c4.z = s h, c4.w = (tx + 1) h, c5.x = (ty + 1) h, c5.y = h with
+// h = image_size / 2; flame_decode_split.hip's pre-pass): head_mesh.py:39-43 as one fma per component instead of four operations --
+// within 2^-23 of 256 px of the form above, fewer roundings against float64.
+__device__ __forceinline__ VertexOut vertex_math_folded(const EpiCtx& cx, float4 c0, float4 c1, float4 c2, float4 c3, float4 c4, float4 c5, float jx, float jy, float jz,
+                                                        float ex, float ey, float ez, float W, float w2) {
+    const float dx = ex - jx, dy = ey - jy, dz = ez - jz;
+    const float qx = __builtin_fmaf(c0.z, dz, __builtin_fmaf(c0.y, dy, c0.x * dx));
+    const float qy = __builtin_fmaf(c1.y, dz, __builtin_fmaf(c1.x, dy, c0.w * dx));
+    const float qz = __builtin_fmaf(c2.x, dz, __builtin_fmaf(c1.w, dy, c1.z * dx));
+    const float px = __builtin_fmaf(qx, w2, ex * W), py = __builtin_fmaf(qy, w2, ey * W);
+    const float pz = __builtin_fmaf(w2, qz, W * ez) + kMeshOffsetZ;  // flame.py:224
+    VertexOut o;
+    o.rx = __builtin_fmaf(c2.w, pz, __builtin_fmaf(c2.z, py, c2.y * px));  // flame.py:226-228: R.v with R = [b1 b2 b3]
+    o.ry = __builtin_fmaf(c3.z, pz, __builtin_fmaf(c3.y, py, c3.x * px));
+    o.rz = __builtin_fmaf(c4.y, pz, __builtin_fmaf(c4.x, py, c3.w * px));
+    o.ox = __builtin_fmaf(o.rx, c4.z, c4.w);
+    o.oy = __builtin_fmaf(o.ry, c4.z, c5.x);
+    o.oz = cx.zsign * __builtin_fmaf(o.rz, c4.z, c5.y);
+    return o;
+}
 template <bool TO2D, int VOFF>
 __device__ __forceinline__ void vertex_store(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, const VertexOut& o, int lh, int ln, bool st3, bool stp,
                                              bool stl, unsigned vrow, unsigned bnl) {
@@ -81,6 +101,29 @@ __device__ __forceinline__ void vertex_store(const EpiCtx& cx, __amdgpu_buffer_r
             if (TO2D) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{o.ox, o.oy}), rsp, (int)(vrow * 8u), 8 * VOFF, DAD3D_PIPE_STORE_AUX);
             else __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.ox, o.oy, o.oz}), rsp, (int)(vrow * 12u), 12 * VOFF, DAD3D_PIPE_STORE_AUX);
         }
+    }
+    if (stl) {
+        auto put = [&](int slot) {
+            const unsigned off = (bnl + (unsigned)slot) * 8u;
+            if (cx.lx) *reinterpret_cast<f2u*>(cx.lx + off) = f2u{o.ox, o.oy};
+            if (cx.lp) *reinterpret_cast<i2u*>(cx.lp + off) = i2u{(int)o.ox, (int)o.oy};  // numpy .astype(int): toward zero
+        };
+        put(lh);
+        if (ln >= 0) {  // duplicate indices in the landmark list: the chain goes on
+            put(ln);
+            for (int slot = cx.lmk_next[ln]; slot >= 0; slot = cx.lmk_next[slot]) put(slot);
+        }
+    }
+}
+
+// vertex_store with the byte offsets of the vertex given (the split kernel keeps them per lane across phases)
+template <bool TO2D>
+__device__ __forceinline__ void vertex_store_at(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, const VertexOut& o, int lh, int ln, bool st3,
+                                                bool stp, bool stl, unsigned off3, unsigned offp, unsigned bnl) {
+    if (st3) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.rx, o.ry, o.rz}), rs3, (int)off3, 0, DAD3D_PIPE_STORE_AUX);
+    if (stp) {
+        if (TO2D) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{o.ox, o.oy}), rsp, (int)offp, 0, DAD3D_PIPE_STORE_AUX);
+        else __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.ox, o.oy, o.oz}), rsp, (int)offp, 0, DAD3D_PIPE_STORE_AUX);
     }
     if (stl) {
         auto put = [&](int slot) {
