@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("DAD3D_LIB_PATH") or os.path.join(_HERE, "libdad3d_hip
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = range(5)
 ZERO_ROTATION, TO_2D, MUTATE_PARAMS, FLIP_Z, COMPAT_CROSS_B3 = 0x1, 0x2, 0x4, 0x8, 0x10
 NORMAL_ACCUMULATE = 0x1
-KERNEL_AUTO, KERNEL_TWO_ROLE, KERNEL_PIPELINED, KERNEL_SPLIT_BF16 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_TWO_ROLE, KERNEL_PIPELINED, KERNEL_SPLIT_BF16, KERNEL_SPLIT_F16 = 0, 1, 2, 3, 4
 
 
 class Dad3dError(RuntimeError):

@@ -42,6 +42,7 @@ struct FlameConsts {
     int device = 0;
     float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
     float* d_bpack_pipe = nullptr;  // basis of the 20-vertex tiles + jaw-joint columns (flame_decode_pipe.hip); null: model not covered
+    float split_b_scale = 1.0f;     // DAD3D_KERNEL_SPLIT_F16: the power of two its entries are multiplied by in front of their fp16 split
     int n_tiles_pipe = 0;
     float* d_gpack = nullptr;  // basis^T in MFMA fragment order for dad3d_flame_grad_inputs: built by the first training forward
     std::mutex gpack_mutex;
@@ -95,6 +96,7 @@ static int decode_kernel_choice() {
         if (!e) return 0;
         if (e[0] == 'v' && e[1] == '1') return DAD3D_KERNEL_TWO_ROLE;
         if (std::strcmp(e, "split") == 0) return DAD3D_KERNEL_SPLIT_BF16;
+        if (std::strcmp(e, "split_f16") == 0) return DAD3D_KERNEL_SPLIT_F16;
         return std::strcmp(e, "force_pipe") == 0 ? DAD3D_KERNEL_PIPELINED : DAD3D_KERNEL_AUTO;  // "pipe" = the default
     }();
     return choice;
@@ -360,6 +362,11 @@ dad3d_status dad3d_flame_create(const dad3d_flame_model* m, const dad3d_flame_co
     h->c = std::make_shared<FlameConsts>();
     h->c->device = device;
     h->c->n_tiles_pipe = n_tiles_pipe;
+    if (pipe_ok) {
+        float max_abs = 0.0f;
+        for (float v : bpack_pipe) max_abs = std::max(max_abs, std::fabs(v));
+        h->c->split_b_scale = split_basis_scale(max_abs);
+    }
     if (pipe_ok && (st = upload(&h->c->d_bpack_pipe, bpack_pipe))) {
         dad3d_flame_destroy(h.release());
         return st;
@@ -572,6 +579,7 @@ static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, in
     q->c = std::make_shared<FlameConsts>();
     q->c->device = h->device;
     q->c->n_tiles_pipe = nt_pipe;
+    q->c->split_b_scale = h->c->split_b_scale;  // a subset of the parent's entries: its scale holds
     dad3d_status st;
     if ((st = upload(&q->c->d_bpack, sub)) || (st = upload(&q->c->d_jdirs, jdirs)) || (st = upload(&q->c->d_j0, j0)) ||
         (st = upload(&q->c->d_w8, w8s)) || (st = upload(&q->d_lmk_head, head2)) || (st = upload(&q->d_lmk_next, next)) ||
@@ -648,15 +656,17 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     const int choice = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
     const bool pipe_covers = h->c->d_bpack_pipe && h->d_vtab && !posed && !(flags & (DAD3D_COMPAT_CROSS_B3 | DAD3D_ZERO_ROTATION)) &&
                              (size_t)batch * h->n_verts * 12 < ((size_t)1 << 31) && (size_t)batch * std::max(h->n_lmk, 1) * 8 < ((size_t)1 << 31);
-    if ((choice == DAD3D_KERNEL_PIPELINED || choice == DAD3D_KERNEL_SPLIT_BF16) && !pipe_covers) {
+    const bool split = choice == DAD3D_KERNEL_SPLIT_BF16 || choice == DAD3D_KERNEL_SPLIT_F16;
+    if ((choice == DAD3D_KERNEL_PIPELINED || split) && !pipe_covers) {
         set_error("dad3d_flame_decode: the %s kernel does not cover this launch (model, flags or output size)",
-                  choice == DAD3D_KERNEL_PIPELINED ? "pipelined" : "bf16x3 split");
+                  choice == DAD3D_KERNEL_PIPELINED ? "pipelined" : "split");
         return DAD3D_E_UNSUPPORTED;
     }
-    if (choice == DAD3D_KERNEL_SPLIT_BF16) {
-        // The gated bf16x3 exact-product split (flame_decode_split.hip): same model coverage, same pack, same epilogue as the pipelined
-        // kernel; the contraction differs (and is the more accurate of the two: profiles/r06_split_error.md). Two launches.
-        DAD3D_REQUIRE(!h->d_trace, "dad3d_flame_decode: the bf16x3 split kernel has no trace stamps");
+    if (split) {
+        // The gated exact-product splits (flame_decode_split.hip; bf16 x 3 planes x 6 products, or fp16 x 2 planes x 3 products): same
+        // model coverage, same pack, same epilogue as the pipelined kernel; the contraction differs (and is more accurate than the
+        // fp32 MFMA chain in both forms: profiles/r06_split_error.md). Two launches.
+        DAD3D_REQUIRE(!h->d_trace, "dad3d_flame_decode: the split kernels have no trace stamps");
         const int n_phase = (batch + kSplitRows - 1) / kSplitRows;
         if (n_phase > h->split_cap) {
             hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
@@ -682,6 +692,7 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         sa.lmk_xy = lmk_xy;
         sa.lmk_px = lmk_px;
         sa.aplanes = h->d_split_a;
+        sa.b_scale = h->c->split_b_scale;
         sa.n_params = h->lay.n_params;
         sa.batch = batch;
         sa.n_phase = n_phase;
@@ -690,7 +701,7 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         sa.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
         sa.image_size = h->image_size;
         sa.flags = flags & 0xFFu;
-        dad3d_status st = launch_flame_decode_split(sa, s);
+        dad3d_status st = launch_flame_decode_split(sa, choice, s);
         if (st) return st;
         if (h->profiling) ++h->prof_launches;
         return DAD3D_OK;
@@ -844,7 +855,7 @@ dad3d_status dad3d_flame_readjust_params(dad3d_flame* h, float* params, int batc
 }
 
 dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which) {
-    DAD3D_REQUIRE(h && which >= DAD3D_KERNEL_AUTO && which <= DAD3D_KERNEL_SPLIT_BF16, "dad3d_flame_select_kernel: bad argument");
+    DAD3D_REQUIRE(h && which >= DAD3D_KERNEL_AUTO && which <= DAD3D_KERNEL_SPLIT_F16, "dad3d_flame_select_kernel: bad argument");
     h->kernel_choice = which;
     return DAD3D_OK;
 }

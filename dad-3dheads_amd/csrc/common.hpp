@@ -157,8 +157,9 @@ inline void pipe_chunking(int n_tiles, int n_half, int* chunk_half, int* n_chunk
 dad3d_status launch_flame_decode_pipe(const PipeArgs& a, hipStream_t s);
 size_t flame_decode_pipe_lds_bytes();
 
-// The bf16x3 exact-product split of the same decode (flame_decode_split.hip, round 6; gated: DAD3D_KERNEL_SPLIT_BF16). Two launches:
-// a pre-pass that splits the params rows into three bf16 planes and computes the per-image constants once, and the tile kernel, which
+// The exact-product splits of the same decode (flame_decode_split.hip, round 6; gated: DAD3D_KERNEL_SPLIT_BF16 -- three bf16 planes, six
+// products -- and DAD3D_KERNEL_SPLIT_F16 -- two fp16 planes, three products). Two launches:
+// a pre-pass that splits the params rows into planes and computes the per-image constants once, and the tile kernel, which
 // reads the pipelined kernel's basis pack as it is and walks the batch in phases of 16 images.
 constexpr int kSplitRows = 16;        // images per phase: one MFMA row block
 constexpr int kSplitKGroups = 13;     // K = 416 in MFMA groups of 32
@@ -177,11 +178,13 @@ struct SplitArgs {
     int32_t* lmk_px;         // [B,n_lmk,2] or null
     char* aplanes;           // [n_phase][kSplitBlockBytes] scratch, pre-pass -> tile kernel: the params rows as bf16 planes, then the
                              // per-image constants D 9 | G 9 | s tx ty | pad of the phase
+    float b_scale;           // DAD3D_KERNEL_SPLIT_F16: the power of two the basis is multiplied by in front of its fp16 split (split_basis_scale)
     int n_params, batch, n_phase, n_tiles, n_verts, n_lmk;
     float image_size;
     unsigned flags;
 };
-dad3d_status launch_flame_decode_split(const SplitArgs& a, hipStream_t s);
+dad3d_status launch_flame_decode_split(const SplitArgs& a, int form, hipStream_t s);  // form: DAD3D_KERNEL_SPLIT_BF16 | DAD3D_KERNEL_SPLIT_F16
+float split_basis_scale(float max_abs);
 size_t flame_decode_split_lds_bytes();
 
 // Backward of the per-vertex half of the decode (flame_backward.hip). Per-image constants, natural joint order:

@@ -29,15 +29,29 @@
 //   * the k order inside an MFMA is the pack's: lane (q, n) of group g holds k = 32 g + 16 h + 4 q + i (h = 0, 1; i = 0..3), so the
 //     pre-pass stores a row's element k at position 32 g + 8 q + 4 h + i and both operands are one aligned 16-byte read per lane.
 //
+// Two forms of the split, one kernel body (template parameter S):
+//   Bf16x3  the above: three bf16 planes per operand, six products per K = 32 (DAD3D_KERNEL_SPLIT_BF16).
+//   F16x2   x S = h1 + h2 with h = fp16 (11 significant bits each: 22 in two planes, the remainder <= 2^-23 |x|), THREE products per
+//           K = 32 -- hi += h1 g1, lo += h1 g2 + h2 g1; the dropped h2 g2 is 2^-22 |a b| -- on v_mfma_f32_16x16x32_f16: half the
+//           matrix instructions, two thirds of the A bytes through LDS and of the basis registers (DAD3D_KERNEL_SPLIT_F16). fp16 has
+//           five exponent bits: the operands are scaled by powers of two (exact) so that no residual underflows -- the params rows by
+//           16 (|x| up to 4094; beyond, the row -- and only the row -- is inf/NaN), the basis by the largest power of two that keeps its
+//           largest entry below 16384 (chosen by the host when the pack is built) -- and the accumulators scaled back when parked.
+//           Measured against float64 (tools/split_probe.hip): max 4.6e-8 / rms 7.3e-9, between the bf16x3 form (3.0e-8 / 5.0e-9) and the
+//           fp32 MFMA chain (9.3e-8 / 1.46e-8). Why it exists: the bf16x3 kernel is bound by LDS bytes in cycles and by the matrix pipe's
+//           switching power in clock (profiles/r06_kernel_log.md section 8); this form moves less of both.
+//
 // Reference arithmetic being replaced: smplx.lbs.blend_shapes + pose correctives through model_training/model/flame.py:212-221.
 #pragma clang fp contract(off)
 #include "common.hpp"
 #include "flame_math.hpp"
 #include "flame_pipe_epilogue.hpp"
 
-#ifndef DAD3D_SPLIT_ABLATE  // diagnostics builds only (tools/build_variant.sh): 1 = no finishing, 2 = no staging after the second phase,
-#define DAD3D_SPLIT_ABLATE 0  // 4 = no MFMAs, 8 = no parking, 16 = no fragment prefetch behind the barrier, 256 = no stores,
-#endif                        // 512 = no finishing arithmetic. Results wrong, timing meaningful. 0 in the product
+#ifndef DAD3D_SPLIT_ABLATE  // diagnostics builds only (tools/build_variant.sh); results wrong, timing meaningful; 0 in the product. Tile kernel:
+#define DAD3D_SPLIT_ABLATE 0  // 1 = no finishing, 2 = no staging after the second phase, 4 = no MFMAs, 8 = no parking, 16 = no fragment prefetch
+#endif                        // behind the barrier, 256 = no stores, 512 = no finishing arithmetic. Pre-pass: 2048 = empty, 4096 = writes the scratch
+                              // once, 8192 = constants left zero, 16384 = planes zero. -DDAD3D_SPLIT_CLOCKS: prints the shader clock of a launch
+                              // (the zero-data builds run 20 % FASTER: the clock, profiles/r06_kernel_log.md section 8)
 
 #ifndef DAD3D_SPLIT_FIN_PRIO
 #define DAD3D_SPLIT_FIN_PRIO 1
@@ -50,6 +64,7 @@ namespace {
 using namespace pipe;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TV = kPipeTileVerts;      // vertices per tile
@@ -58,12 +73,33 @@ constexpr int OS = 76;                  // accumulator tile row stride (floats),
 constexpr int QB = kSplitRows;          // images per phase: one MFMA row block
 constexpr int RS = kSplitRowBytes;      // bytes per plane row: 416 bf16 + 16 bytes (RS / 4 = 212 = 20 (mod 64): sixteen rows' 16-byte
                                         // reads at one offset cover the 64 banks once)
-constexpr int PLN = kSplitPlaneBytes;   // the planes of a phase [3][16 rows][RS], padded to a multiple of 1 KB (one wave's global_load_lds)
-constexpr int CST = kSplitConstBytes;   // its constants [16][24 floats], padded likewise
-constexpr int BLK = kSplitBlockBytes;   // a phase in HBM: planes | constants
+constexpr int CST = kSplitConstBytes;   // the constants of a phase [16][24 floats], padded to a multiple of 1 KB (one wave's global_load_lds)
 constexpr int kNumBeta = 400;
 constexpr int kPairs = QB * TV;         // (image, vertex) pairs of a phase: 320 = five wave-wide finishing calls
+// the two forms of the split
+struct Bf16x3 {
+    typedef __bf16 elem;
+    typedef bf16x8 vec8;
+    static constexpr int NPL = 3;                      // planes per operand
+    static constexpr int PLN = kSplitPlaneBytes;       // the planes of a phase [NPL][16 rows][RS], padded to a multiple of 1 KB
+    static constexpr float kScaleA = 1.0f;
+    static constexpr bool kScaled = false;
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+struct F16x2 {
+    typedef _Float16 elem;
+    typedef f16x8 vec8;
+    static constexpr int NPL = 2;
+    static constexpr int PLN = (2 * kSplitRows * kSplitRowBytes + 1023) / 1024 * 1024;
+    static constexpr float kScaleA = 16.0f;            // params rows x 16: residuals of |x| >= 2^-7 stay normal, |x| up to 4094 representable
+    static constexpr bool kScaled = true;
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+static_assert(Bf16x3::PLN + CST == kSplitBlockBytes && F16x2::PLN <= Bf16x3::PLN, "the scratch is sized for the larger form");
+
+template <class S>
 struct Lds {
+    static constexpr int PLN = S::PLN;
     static constexpr int a_off = 0;                          // [3][PLN]         A planes, three images: one multiplied, one landed, one in flight
     static constexpr int c_off = a_off + 3 * PLN;            // [8][CST]         per-image constants, a ring of eight phases (staged two
                                                              //                  windows ahead of the GEMM, consumed two behind it)
@@ -78,8 +114,9 @@ __device__ __forceinline__ void phase_barrier() {  // does not drain the wave's 
 }
 
 // x -> (bf16(x), x - bf16(x)): round to nearest even; the residual is exact (it has at most 16 significant bits)
-__device__ __forceinline__ f32x8 peel(f32x8 r, bf16x8& plane) {
-    plane = __builtin_convertvector(r, bf16x8);
+template <class V>
+__device__ __forceinline__ f32x8 peel(f32x8 r, V& plane) {
+    plane = __builtin_convertvector(r, V);
     return r - __builtin_convertvector(plane, f32x8);
 }
 
@@ -91,12 +128,16 @@ __device__ __forceinline__ void glds_1k(const char* gsrc_lane, char* lds_base) {
 }  // namespace
 
 // ---- pre-pass: one workgroup per image (rows past the batch: zero planes) --------------------------------------------------------
+template <class S>
 __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
+    constexpr int PLN = S::PLN, BLK = S::PLN + CST;
     const int b = blockIdx.x, t = threadIdx.x, P = a.n_params;
+    if (DAD3D_SPLIT_ABLATE & 2048) return;  // (diagnostics: what the second launch costs by existing)
     const bool live = b < a.batch;
     float* prow = a.params + (size_t)min(b, a.batch - 1) * P;
     char* blk = a.aplanes + (size_t)(b / QB) * BLK;
     char* row = blk + (size_t)(b % QB) * RS;
+    if ((DAD3D_SPLIT_ABLATE & 4096) && *reinterpret_cast<const volatile unsigned*>(row) != 0u) return;  // (diagnostics: write the scratch ONCE -- real data, L2-resident afterwards)
     // [400,403) jaw | [403,409) 6-DoF rotation | [409,412) translation | [412] scale   (FlameParams.from_3dmm, flame.py:48-73)
     // constants of an image (24 floats): D = R_jaw - I (9) | G = 6-DoF rotation (9) | s h | (tx + 1) h | (ty + 1) h | h
     float D[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -113,22 +154,22 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (t - kNumBeta / 2 == i) x = tail[2 * i], y = tail[2 * i + 1];
-        if (!live) x = y = 0.f;
+        if (!live || (DAD3D_SPLIT_ABLATE & 16384)) x = y = 0.f;  // (16384: zero planes, real constants)
         // position of k inside its group of 32: the basis pack's k order (lane q of the MFMA holds k = 16 h + 4 q + i)
         const int g = k0 >> 5, h = (k0 >> 4) & 1, q = (k0 >> 2) & 3, i = k0 & 3;
         const int pos = 32 * g + 8 * q + 4 * h + i;
-        float rx = x, ry = y;
+        float rx = x * S::kScaleA, ry = y * S::kScaleA;  // (a power of two: exact)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            const __bf16 hx = (__bf16)rx, hy = (__bf16)ry;
+        for (int pl = 0; pl < S::NPL; ++pl) {
+            const typename S::elem hx = (typename S::elem)rx, hy = (typename S::elem)ry;
             rx = rx - (float)hx, ry = ry - (float)hy;
             const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, hx) | ((unsigned)__builtin_bit_cast(unsigned short, hy) << 16);
             *reinterpret_cast<unsigned*>(row + (size_t)pl * QB * RS + 2 * pos) = packed;
         }
-    } else if (t < 220) {  // the 16 bytes of row padding of each plane (copied into LDS with the rest, never multiplied)
+    } else if (t < 208 + 4 * S::NPL) {  // the 16 bytes of row padding of each plane (copied into LDS with the rest, never multiplied)
         const int pl = (t - 208) >> 2, w = (t - 208) & 3;
         *reinterpret_cast<unsigned*>(row + (size_t)pl * QB * RS + 832 + 4 * w) = 0u;
-    } else if (t == 255) {
+    } else if (t == 255 && !(DAD3D_SPLIT_ABLATE & 8192)) {  // (8192: real planes, constants left zero)
         const float rot6[6] = {prow[403], prow[404], prow[405], prow[406], prow[407], prow[408]};
         float G[9];
         rot6_to_matrix_lean(rot6, G);
@@ -157,13 +198,15 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
 // constants into ring slot (p + 2) & 7, then waits for phase p + 1's (requested a window earlier: a global -> LDS round trip is as
 // long as a window). Finishers, window p: tile p - 2 out of tile pair p & 1 (parked behind B(p - 2), visible behind B(p - 1); written
 // next behind B(p)), constants from ring slot (p - 2) & 7 (written next in window p + 4).
-template <bool TO2D>
+template <class S, bool TO2D>
 __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a) {
+    typedef typename S::vec8 vec8;
+    constexpr int NPL = S::NPL, PLN = S::PLN, BLK = S::PLN + CST;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* abuf = smem + Lds::a_off;
-    char* cring = smem + Lds::c_off;
-    float* otile = reinterpret_cast<float*>(smem + Lds::o_off);
-    float4* vt_lds = reinterpret_cast<float4*>(smem + Lds::v_off);
+    char* abuf = smem + Lds<S>::a_off;
+    char* cring = smem + Lds<S>::c_off;
+    float* otile = reinterpret_cast<float*>(smem + Lds<S>::o_off);
+    float4* vt_lds = reinterpret_cast<float4*>(smem + Lds<S>::v_off);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the roles branch and loop on SGPRs, not under exec masks
@@ -172,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
 
     if (wave == 4) {
         // ====================================================== stager wave ===========================================================
-        auto stage = [&](int p) {  // 40 + 2 requests of 1 KB
+        auto stage = [&](int p) {  // PLN / 1 KB + 2 requests of 1 KB (40 + 2 | 27 + 2)
             const char* src = a.aplanes + (size_t)p * BLK + 16 * lane;
             char* dst = abuf + (p % 3) * PLN;
 #if defined(DAD3D_SPLIT_NO_GLDS)  // diagnostics: the same copy through registers -- a SLOW stager, the deterministic repro of section 4 of the log
@@ -193,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
             for (int i = 0; i < CST / 1024; ++i) glds_1k(src + PLN + 1024 * i, cring + (p & 7) * CST + 1024 * i);
 #endif
         };
-        // this wave's only vector-memory operations are the 42 requests of a stage, so "phase p + 1 has landed" is a COUNTED wait:
+        // this wave's only vector-memory operations are the 42 (29) requests of a stage, so "phase p + 1 has landed" is a COUNTED wait:
         // everything but the stage issued after it (requests complete in order)
         constexpr int kStageOps = PLN / 1024 + CST / 1024;
         static_assert(kStageOps <= 63, "vmcnt is a 6-bit counter");
@@ -344,85 +387,107 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
             }
 #pragma unroll
     for (int h = 0; h < 2; ++h) rawt[h] = bsrc[(size_t)((24 + h) * 4 + c0) * 64];
-    bf16x8 bp[6][2][3], bt[3];  // the wave's basis slice as three planes, resident for the launch
+    vec8 bp[6][2][NPL], bt[NPL];  // the wave's basis slice as NPL planes, resident for the launch
     const char* afrag0 = abuf + (lane & 15) * RS + (lane >> 4) * 16;
     float* const ot0 = otile + kh * (QB * OS) + ((lane >> 4) * 4) * OS + (lane & 15);
-    auto planes = [&](const float4& lo, const float4& hi, bf16x8 (&out)[3]) {
-        f32x8 r = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        r = peel(r, out[0]);
-        r = peel(r, out[1]);
-        out[2] = __builtin_convertvector(r, bf16x8);
+    const float b_scale = S::kScaled ? a.b_scale : 1.0f;  // F16x2: the basis x a power of two (exact), so that no residual underflows
+    const float out_scale = S::kScaled ? 1.0f / (S::kScaleA * a.b_scale) : 1.0f;
+    auto planes = [&](const float4& lo, const float4& hi, vec8 (&out)[NPL]) {
+        float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (S::kScaled) {  // element by element, opaque to the vectoriser: a vector multiply becomes v_pk_mul_f32, which this file keeps out
+#pragma unroll           // (section 4 of the log)
+            for (int i = 0; i < 8; ++i) asm("v_mul_f32 %0, %1, %2" : "=v"(e[i]) : "v"(e[i]), "v"(b_scale));
+        }
+        f32x8 r = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]};
+#pragma unroll
+        for (int pl = 0; pl + 1 < NPL; ++pl) r = peel(r, out[pl]);
+        out[NPL - 1] = __builtin_convertvector(r, vec8);
     };
-    auto read_frags = [&](int p, int g, bf16x8 (&dst)[3]) {
+    auto read_frags = [&](int p, int g, vec8 (&dst)[NPL]) {
         const char* ab = afrag0 + (p % 3) * PLN + 64 * g;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(ab + pl * (QB * RS));
+        for (int pl = 0; pl < NPL; ++pl) dst[pl] = *reinterpret_cast<const vec8*>(ab + pl * (QB * RS));
     };
-    bf16x8 af[3];  // the fragments the next MFMAs multiply
+    vec8 af[NPL];  // the fragments the next MFMAs multiply
+    // the products of one (A fragment group, B column block) -- Bf16x3: hi += a1 b1, lo += a1 b3 + a3 b1 + a2 b2 + a1 b2 + a2 b1;
+    // F16x2: hi += h1 g1, lo += h1 g2 + h2 g1 -- two column blocks interleaved: no MFMA waits for the one in front of it
+    auto products2 = [&](const vec8 (&x)[NPL], const vec8 (&b0)[NPL], const vec8 (&b1)[NPL], f32x4& lo0, f32x4& hi0, f32x4& lo1, f32x4& hi1) {
+        if constexpr (NPL == 3) {
+            lo0 = S::mfma(x[0], b0[2], lo0), lo1 = S::mfma(x[0], b1[2], lo1);
+            lo0 = S::mfma(x[2], b0[0], lo0), lo1 = S::mfma(x[2], b1[0], lo1);
+            lo0 = S::mfma(x[1], b0[1], lo0), lo1 = S::mfma(x[1], b1[1], lo1);
+            lo0 = S::mfma(x[0], b0[1], lo0), lo1 = S::mfma(x[0], b1[1], lo1);
+            lo0 = S::mfma(x[1], b0[0], lo0), lo1 = S::mfma(x[1], b1[0], lo1);
+            hi0 = S::mfma(x[0], b0[0], hi0), hi1 = S::mfma(x[0], b1[0], hi1);
+        } else {
+            lo0 = S::mfma(x[0], b0[1], lo0), lo1 = S::mfma(x[0], b1[1], lo1);
+            lo0 = S::mfma(x[1], b0[0], lo0), lo1 = S::mfma(x[1], b1[0], lo1);
+            hi0 = S::mfma(x[0], b0[0], hi0), hi1 = S::mfma(x[0], b1[0], hi1);
+        }
+    };
+    auto products1 = [&](const vec8 (&x)[NPL], const vec8 (&b0)[NPL], f32x4& lo0, f32x4& hi0) {
+        if constexpr (NPL == 3) {
+            lo0 = S::mfma(x[0], b0[2], lo0);
+            hi0 = S::mfma(x[0], b0[0], hi0);
+            lo0 = S::mfma(x[2], b0[0], lo0);
+            lo0 = S::mfma(x[1], b0[1], lo0);
+            lo0 = S::mfma(x[0], b0[1], lo0);
+            lo0 = S::mfma(x[1], b0[0], lo0);
+        } else {
+            lo0 = S::mfma(x[0], b0[1], lo0);
+            hi0 = S::mfma(x[0], b0[0], hi0);
+            lo0 = S::mfma(x[1], b0[0], lo0);
+        }
+    };
 
     // one phase: per column block, hi += a1 b1 and lo += the five smaller products (measured as accurate as three accumulators by order
     // of magnitude, tools/split_probe.hip); FIRST: the basis slice is still arriving and is split slot by slot in front of its first use
     auto phase = [&](int p, auto first) {
         constexpr bool FIRST = decltype(first)::value;
         f32x4 hi0 = {0.f, 0.f, 0.f, 0.f}, lo0 = hi0, hi1 = hi0, lo1 = hi0;
-        bf16x8 an[3] = {};
+        vec8 an[NPL] = {};
 #pragma unroll
         for (int sl = 0; sl < 6; ++sl) {
             if (FIRST) planes(raw[sl][0][0], raw[sl][0][1], bp[sl][0]), planes(raw[sl][1][0], raw[sl][1][1], bp[sl][1]);
             read_frags(p, sl < 5 ? gbase + sl + 1 : 12, an);  // the tail group last
             __builtin_amdgcn_sched_barrier(0);
             if ((DAD3D_SPLIT_ABLATE & 4) && !FIRST) {
-                hi0 += __builtin_bit_cast(f32x4, af[0]) + __builtin_bit_cast(f32x4, af[1]) + __builtin_bit_cast(f32x4, af[2]);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) hi0 += __builtin_bit_cast(f32x4, af[pl]);
             } else {
-                // the two column blocks alternate: no MFMA waits for the one in front of it
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][0][2], lo0, 0, 0, 0);
-                lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][1][2], lo1, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bp[sl][0][0], lo0, 0, 0, 0);
-                lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bp[sl][1][0], lo1, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bp[sl][0][1], lo0, 0, 0, 0);
-                lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bp[sl][1][1], lo1, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][0][1], lo0, 0, 0, 0);
-                lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][1][1], lo1, 0, 0, 0);
-                lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bp[sl][0][0], lo0, 0, 0, 0);
-                lo1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bp[sl][1][0], lo1, 0, 0, 0);
-                hi0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][0][0], hi0, 0, 0, 0);
-                hi1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bp[sl][1][0], hi1, 0, 0, 0);
+                products2(af, bp[sl][0], bp[sl][1], lo0, hi0, lo1, hi1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[pl] = an[pl];
+            for (int pl = 0; pl < NPL; ++pl) af[pl] = an[pl];
         }
         // every fragment of A(p) is in registers (the tail group's in `af`): the image may be overwritten, A(p + 1) has landed
         phase_barrier();  // B(p)
         if (!(DAD3D_SPLIT_ABLATE & 16) && p + 1 < NP) read_frags(p + 1, gbase, an);
         if (FIRST) planes(rawt[0], rawt[1], bt);
         __builtin_amdgcn_sched_barrier(0);
-        if (!((DAD3D_SPLIT_ABLATE & 4) && !FIRST)) {  // the tail group, column block c0 only
-            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[2], lo0, 0, 0, 0);
-            hi0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[0], hi0, 0, 0, 0);
-            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bt[0], lo0, 0, 0, 0);
-            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bt[1], lo0, 0, 0, 0);
-            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bt[1], lo0, 0, 0, 0);
-            lo0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bt[0], lo0, 0, 0, 0);
-        }
+        if (!((DAD3D_SPLIT_ABLATE & 4) && !FIRST)) products1(af, bt, lo0, hi0);  // the tail group, column block c0 only
         __builtin_amdgcn_sched_barrier(0);
         // accumulators -> partial tile kh [image][column], small + large; D layout: row = (lane >> 4) * 4 + reg, column = lane & 15
         float* ot = ot0 + (p & 1) * (2 * QB * OS);
         if (!(DAD3D_SPLIT_ABLATE & 8)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c1] = lo1[r] + hi1[r];
+            for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c1] = S::kScaled ? (lo1[r] + hi1[r]) * out_scale : lo1[r] + hi1[r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c0] = lo0[r] + hi0[r];
+            for (int r = 0; r < 4; ++r) ot[r * OS + 16 * c0] = S::kScaled ? (lo0[r] + hi0[r]) * out_scale : lo0[r] + hi0[r];
         } else if (lo0[0] + hi0[0] + lo1[0] + hi1[0] == 123.456f) ot[0] = 0.f;
         if ((DAD3D_SPLIT_ABLATE & 16) && p + 1 < NP) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             read_frags(p + 1, gbase, an);
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[pl] = an[pl];
+        for (int pl = 0; pl < NPL; ++pl) af[pl] = an[pl];
     };
 
     phase_barrier();  // S0
+#if defined(DAD3D_SPLIT_CLOCKS)  // diagnostics: the shader clock the launch ran at (s_memtime cycles per 10 ns tick of s_memrealtime)
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
     read_frags(0, gbase, af);
     phase(0, std::true_type{});
 #pragma unroll 1
@@ -436,25 +501,50 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
         return;
     }
     phase_barrier();  // E
+#if defined(DAD3D_SPLIT_CLOCKS)
+    if (tile == 17 && tid == 130) {
+        unsigned* cnt = reinterpret_cast<unsigned*>(a.aplanes + PLN + 1536);  // padding behind the constants of phase 0
+        const unsigned n = atomicAdd(cnt, 1u);
+        const long long dc = clock64() - clk0, dw = wall_clock64() - wall0;
+        if ((n & 255u) == 255u) printf("CLK n_phase %d cycles %lld ticks %lld MHz %.0f cycles/phase %.0f\n", NP, dc, dw, (double)dc / (dw * 10.0) * 1e3, (double)dc / NP);
+    }
+#endif
 }
 
-size_t flame_decode_split_lds_bytes() { return (size_t)Lds::total; }
+size_t flame_decode_split_lds_bytes() { return (size_t)Lds<Bf16x3>::total; }
 
-dad3d_status launch_flame_decode_split(const SplitArgs& a, hipStream_t s) {
-    static PerDeviceOnce attr_done;
+namespace {
+template <class S>
+dad3d_status launch_split(const SplitArgs& a, hipStream_t s, PerDeviceOnce& attr_done) {
     const int dev = PerDeviceOnce::current();
-    const size_t lds = flame_decode_split_lds_bytes();
+    const size_t lds = (size_t)Lds<S>::total;
     if (!attr_done.done(dev)) {
-        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_split_kernel<true>),
-                              reinterpret_cast<const void*>(&flame_decode_split_kernel<false>)})
+        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_split_kernel<S, true>),
+                              reinterpret_cast<const void*>(&flame_decode_split_kernel<S, false>)})
             DAD3D_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done.set(dev);
     }
-    hipLaunchKernelGGL(split_params_kernel, dim3(a.n_phase * kSplitRows), dim3(256), 0, s, a);
-    if ((a.flags & DAD3D_TO_2D) || !a.proj) hipLaunchKernelGGL(flame_decode_split_kernel<true>, dim3(a.n_tiles), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(flame_decode_split_kernel<false>, dim3(a.n_tiles), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(split_params_kernel<S>, dim3(a.n_phase * kSplitRows), dim3(256), 0, s, a);
+    if ((a.flags & DAD3D_TO_2D) || !a.proj) hipLaunchKernelGGL((flame_decode_split_kernel<S, true>), dim3(a.n_tiles), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((flame_decode_split_kernel<S, false>), dim3(a.n_tiles), dim3(512), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
+}
+}  // namespace
+
+// form: DAD3D_KERNEL_SPLIT_BF16 or DAD3D_KERNEL_SPLIT_F16 (then a.b_scale = the power of two of split_basis_scale())
+dad3d_status launch_flame_decode_split(const SplitArgs& a, int form, hipStream_t s) {
+    static PerDeviceOnce attr_bf16, attr_f16;
+    if (form == DAD3D_KERNEL_SPLIT_F16) return launch_split<F16x2>(a, s, attr_f16);
+    return launch_split<Bf16x3>(a, s, attr_bf16);
+}
+
+// F16x2: the largest power of two that keeps max |basis| x scale <= 16384 (fp16 overflows at 65504; the headroom is for nothing but
+// comfort -- the products are exact in the fp32 accumulator at any scale), at most 2^24
+float split_basis_scale(float max_abs) {
+    float s = 1.0f;
+    while (s < 16777216.0f && max_abs * (s * 2.0f) <= 16384.0f) s *= 2.0f;
+    return s;
 }
 
 }  // namespace dad3d

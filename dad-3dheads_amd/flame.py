@@ -197,11 +197,12 @@ class FLAMELayer(torch.nn.Module):
 
     def select_kernel(self, which: str = "auto") -> None:
         """Diagnostics / A-B timing: "auto" (default: the pipelined single-role kernel wherever it covers the launch), "two_role"
-        (the kernel of rounds 1-3), "pipelined" (raise instead of falling back) or "split_bf16" (the gated bf16x3 exact-product split
-        of the contraction, csrc/flame_decode_split.hip: not bit-identical to the default, measured more accurate; raises where the
-        pipelined kernel would). dad3d_flame_select_kernel."""
+        (the kernel of rounds 1-3), "pipelined" (raise instead of falling back), "split_bf16" or "split_f16" (the gated exact-product
+        splits of the contraction, csrc/flame_decode_split.hip -- three bf16 planes x six products / two fp16 planes x three products:
+        not bit-identical to the default, both measured more accurate; raise where the pipelined kernel would).
+        dad3d_flame_select_kernel."""
         code = {"auto": _lib.KERNEL_AUTO, "two_role": _lib.KERNEL_TWO_ROLE, "pipelined": _lib.KERNEL_PIPELINED,
-                "split_bf16": _lib.KERNEL_SPLIT_BF16}[which]
+                "split_bf16": _lib.KERNEL_SPLIT_BF16, "split_f16": _lib.KERNEL_SPLIT_F16}[which]
         _lib.check(self._lib.dad3d_flame_select_kernel(self._handle, code))
 
     def decode_tables(self):

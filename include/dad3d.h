@@ -204,12 +204,17 @@ DAD3D_EXPORT dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned*
  * planes with exact residuals and six of the nine plane products are accumulated in fp32 -- measured MORE accurate against float64 than
  * the fp32 MFMA chain (profiles/r06_split_error.md) and held to the same bars by the same tests, but NOT bit-identical to the default
  * kernel; same model coverage as the pipelined kernel (DAD3D_E_UNSUPPORTED otherwise), two launches per decode, its first call at a
- * batch size allocates (warm up before capturing a graph). The environment variable DAD3D_DECODE_KERNEL=v1|force_pipe|split sets the
+ * batch size allocates (warm up before capturing a graph). DAD3D_KERNEL_SPLIT_F16 = the same kernel with the operands as TWO fp16
+ * planes (22 significant bits; params rows x 16 and the basis x a power of two chosen at dad3d_flame_create so that no residual
+ * underflows -- exact scalings) and three products: half the matrix instructions, about 1.4x the speed of the bf16 form at large
+ * batches, error against float64 between the bf16 form's and the fp32 chain's (same file); a params entry beyond +-4094 makes ITS
+ * row inf/NaN in this form only. The environment variable DAD3D_DECODE_KERNEL=v1|force_pipe|split|split_f16 sets the
  * process-wide default for handles that have not chosen (A/B timing; anything else = automatic). */
 #define DAD3D_KERNEL_AUTO 0
 #define DAD3D_KERNEL_TWO_ROLE 1
 #define DAD3D_KERNEL_PIPELINED 2
 #define DAD3D_KERNEL_SPLIT_BF16 3
+#define DAD3D_KERNEL_SPLIT_F16 4
 DAD3D_EXPORT dad3d_status dad3d_flame_select_kernel(dad3d_flame* h, int which);
 /* Diagnostics: a DEVICE buffer of `capacity` uint64 entries that every wave of the decode kernel fills with shader-clock stamps
  * (32 entries per wave; slots 12 / 13 = the 100 MHz wall clock at the wave's start / end); NULL switches it off. The two kernels

@@ -1,5 +1,5 @@
 """GPU: hypothesis-driven decode calls -- any batch size, any subset of outputs, either projection width, z flip, the side effect on
-or off, landmark lists with duplicates and of any length, both camera profiles, any of the three kernels -- against the CPU oracle through the
+or off, landmark lists with duplicates and of any length, both camera profiles, any of the four kernels -- against the CPU oracle through the
 same Python surface a caller uses. The fixed-case tests pin the known boundaries; this one looks for interplay between options
 (a null output pointer with landmarks on, a ragged last half-block with a one-entry landmark list, ...)."""
 import numpy as np
@@ -19,15 +19,15 @@ TOL_V, TOL_PX = 5e-6, 1e-3
 @pytest.fixture(scope="module")
 def heads(flame_model, static):
     out = {}
-    for kernel in ("auto", "two_role", "split_bf16"):
+    for kernel in ("auto", "two_role", "split_bf16", "split_f16"):
         hm = HeadMesh(flame_model=flame_model, landmarks=np.arange(3, dtype=np.int64), static=static, device=0)
         hm.flame.select_kernel(kernel)
         out[kernel] = hm
     return out
 
 
-@settings(max_examples=180, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-@given(seed=st.integers(0, 2**31 - 1), batch=st.one_of(st.integers(1, 70), st.integers(71, 330)), kernel=st.sampled_from(["auto", "two_role", "split_bf16"]),
+@settings(max_examples=240, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), batch=st.one_of(st.integers(1, 70), st.integers(71, 330)), kernel=st.sampled_from(["auto", "two_role", "split_bf16", "split_f16"]),
        want_v=st.booleans(), want_p=st.booleans(), to_2d=st.booleans(), flip_z=st.booleans(), want_lx=st.booleans(), want_lp=st.booleans(),
        mutate=st.booleans(), n_lmk=st.integers(1, 600), profile=st.sampled_from(["crop", "survey"]))
 def test_any_decode_call_matches_the_oracle(heads, flame_consts, seed, batch, kernel, want_v, want_p, to_2d, flip_z, want_lx, want_lp, mutate,

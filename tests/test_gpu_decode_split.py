@@ -1,5 +1,6 @@
-"""GPU: the gated bf16x3 exact-product split of the blend-shape contraction (csrc/flame_decode_split.hip, round 6;
-`select_kernel("split_bf16")`) through the C ABI. Held to the SAME bars as the default fp32 kernel -- reference-generated goldens,
+"""GPU: the gated exact-product splits of the blend-shape contraction (csrc/flame_decode_split.hip, round 6;
+`select_kernel("split_bf16")`: three bf16 planes, six products; `select_kernel("split_f16")`: two fp16 planes, three products) through
+the C ABI, every test on both forms. Held to the SAME bars as the default fp32 kernel -- reference-generated goldens,
 the CPU oracle at every phase boundary, exact gather, integer pixels -- and, first of all, to its measured error against the
 float64 arbiter (oracle/lbs_independent.py) next to the fp32 kernel's: the table goes to gpurun_out/r06_split_error.md (committed as
 profiles/r06_split_error.md). Contraction being replaced: model_training/model/flame.py:212-221 (smplx.lbs.blend_shapes + correctives)."""
@@ -19,14 +20,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_V, TOL_PX = 5e-6, 1e-3  # the bars of tests/test_gpu_decode.py (north star: 1e-4 abs)
 
 
+FORMS = ("split_bf16", "split_f16")
+
+
+def _mesh(flame_model, static, kernel):
+    hm = HeadMesh(flame_model=flame_model, landmarks=landmarks.canonical("445", static), static=static, device=0)
+    hm.flame.select_kernel(kernel)  # the split forms raise where they do not cover the launch, never fall back
+    hm.split_form = kernel
+    return hm
+
+
 @pytest.fixture(scope="module")
-def meshes(flame_model, static):
-    lm = landmarks.canonical("445", static)
-    split = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
-    split.flame.select_kernel("split_bf16")  # raises where it does not cover the launch, never falls back
-    pipe = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
-    pipe.flame.select_kernel("pipelined")
-    return split, pipe
+def pipe_mesh(flame_model, static):
+    return _mesh(flame_model, static, "pipelined")
+
+
+@pytest.fixture(scope="module", params=FORMS)
+def meshes(request, flame_model, static, pipe_mesh):
+    return _mesh(flame_model, static, request.param), pipe_mesh
+
+
+@pytest.fixture(scope="module")
+def both_forms(flame_model, static):
+    return {form: _mesh(flame_model, static, form) for form in FORMS}
 
 
 def _args64(fc):
@@ -45,11 +61,11 @@ def _float64_truth(params, verts, args64):
     return v3d, px
 
 
-def test_error_against_float64_next_to_the_fp32_kernel(meshes, flame_consts):
-    """Error before speed: max and rms distance to the float64 evaluation of the same formula, fp32 kernel and split kernel, at
-    B = 64 / 256 / 2048 and both camera profiles, on 48 vertices of every row. The split must not be worse than 1.5x the fp32
-    kernel on any line (it is measured better: every product enters the accumulator exactly)."""
-    split, pipe = meshes
+def test_error_against_float64_next_to_the_fp32_kernel(both_forms, pipe_mesh, flame_consts):
+    """Error before speed: max and rms distance to the float64 evaluation of the same formula, fp32 kernel and both split forms, at
+    B = 64 / 256 / 2048 and both camera profiles, on 48 vertices of every row. A split must not be worse than 1.5x the fp32
+    kernel on any line (both are measured better: every product enters the accumulator exactly)."""
+    pipe = pipe_mesh
     args64 = _args64(flame_consts)
     rng = np.random.default_rng(6)
     verts = np.sort(rng.choice(5023, 48, replace=False))
@@ -60,7 +76,7 @@ def test_error_against_float64_next_to_the_fp32_kernel(meshes, flame_consts):
             params = synthetic.synthetic_params(batch, seed=600 + batch, profile=profile)
             v64, px64 = _float64_truth(params, verts, args64)
             err = {}
-            for name, hm in (("fp32 (pipelined)", pipe), ("bf16x3 split", split)):
+            for name, hm in (("fp32 (pipelined)", pipe), ("bf16x3 split", both_forms["split_bf16"]), ("fp16x2 split", both_forms["split_f16"])):
                 out = hm.decode(torch.from_numpy(params.copy()).cuda(), to_2d=False, landmarks=False)
                 torch.cuda.synchronize()
                 dv = out["verts3d"][:, vsel].cpu().numpy().astype(np.float64) - v64
@@ -68,13 +84,15 @@ def test_error_against_float64_next_to_the_fp32_kernel(meshes, flame_consts):
                 err[name] = (np.abs(dv).max(), np.sqrt((dv ** 2).mean()), np.abs(dp).max(), np.sqrt((dp ** 2).mean()))
                 lines.append(f"| {profile} | {batch} | {name} | {err[name][0]:.3e} | {err[name][1]:.3e} | {err[name][2]:.3e} | {err[name][3]:.3e} |")
                 assert err[name][0] < TOL_V and err[name][2] < TOL_PX
-            a, b = err["bf16x3 split"], err["fp32 (pipelined)"]
-            for k in range(4):
-                assert a[k] <= 1.5 * b[k], (profile, batch, k, a, b)
-    text = ("# Error of the decode kernels against float64 (oracle/lbs_independent.py), fp32 MFMA chain vs bf16x3 exact-product split\n\n"
+            for form in ("bf16x3 split", "fp16x2 split"):
+                a, b = err[form], err["fp32 (pipelined)"]
+                for k in range(4):
+                    assert a[k] <= 1.5 * b[k], (profile, batch, form, k, a, b)
+    text = ("# Error of the decode kernels against float64 (oracle/lbs_independent.py), fp32 MFMA chain vs the exact-product splits\n\n"
             "Written by tests/test_gpu_decode_split.py on the GPU box: 48 vertices of every row, `3-D` in FLAME model units (north star 1e-4,\n"
             "test bar 5e-6), `px` in pixels of the 256 x 256 frame (test bar 1e-3). Both kernels share the epilogue and the per-image constants;\n"
-            "they differ in the blend-shape contraction only (flame.py:212-221).\n\n" + "\n".join(lines) + "\n")
+            "they differ in the blend-shape contraction only (flame.py:212-221): fp32 MFMA chain | three bf16 planes, six products | two fp16 planes,\n"
+            "three products (and the split forms fold the projection into one fma per component).\n\n" + "\n".join(lines) + "\n")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r06_split_error.md"), "w") as fh:
         fh.write(text)
@@ -182,17 +200,25 @@ def test_split_kernel_duplicate_rows_are_bit_identical_wherever_they_land(meshes
 
 
 def test_split_kernel_poisoned_row_stays_in_its_row(meshes, flame_consts):
-    """A NaN or an infinity in one params row reaches that row's outputs only (torch semantics: the reference would return NaN there)."""
+    """A NaN or an infinity in one params row reaches that row's outputs only (torch semantics: the reference would return NaN there).
+    The fp16 form's documented limit is a row's business too: an entry beyond +-4094 makes THAT row inf/NaN (the bf16 form carries
+    fp32's range)."""
     split, _ = meshes
     params = synthetic.synthetic_params(40, seed=6400)
     bad = params.copy()
     bad[7, 13] = np.nan
     bad[21, 350] = np.inf
+    if split.split_form == "split_f16":
+        bad[33, 5] = 1.0e5
+        big = split.decode(torch.from_numpy(bad).cuda(), to_2d=True, landmarks=False)
+        assert not bool(torch.isfinite(big["verts3d"][33]).all())
+        bad[33, 5] = 4000.0  # inside the range: finite
     good = split.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True, landmarks=False)
     out = split.decode(torch.from_numpy(bad).cuda(), to_2d=True, landmarks=False)
     torch.cuda.synchronize()
-    rest = [i for i in range(40) if i not in (7, 21)]
+    rest = [i for i in range(40) if i not in (7, 21, 33)]
     assert torch.equal(out["verts3d"][rest], good["verts3d"][rest]) and torch.equal(out["proj"][rest], good["proj"][rest])
+    assert bool(torch.isfinite(out["verts3d"][33]).all())
     assert bool(torch.isnan(out["verts3d"][7]).all()) and bool(torch.isnan(out["verts3d"][21]).all())
 
 
@@ -216,7 +242,7 @@ def test_split_kernel_refuses_what_it_does_not_cover_and_replays_from_a_graph(me
         assert torch.equal(out[k], want[k])
     # a fork shares the basis and owns its scratch
     twin = split.fork()
-    twin.flame.select_kernel("split_bf16")
+    twin.flame.select_kernel(split.split_form)
     other = twin.decode(p.clone(), to_2d=True, landmarks=True)
     assert torch.equal(other["proj"], want["proj"])
 
@@ -226,7 +252,7 @@ def test_split_kernel_two_forks_on_two_streams(meshes):
     shared; launches interleaved on two streams return what one stream returns."""
     split, _ = meshes
     twin = split.fork()
-    twin.flame.select_kernel("split_bf16")
+    twin.flame.select_kernel(split.split_form)
     pa = torch.from_numpy(synthetic.synthetic_params(200, seed=6600)).cuda()
     pb = torch.from_numpy(synthetic.synthetic_params(136, seed=6601)).cuda()
     want_a = split.decode(pa.clone(), to_2d=True, landmarks=True)

@@ -3,7 +3,7 @@
 The reference truncates float pixel coordinates (`projected_vertices.astype(int)`, demo_utils.py:42-46). Two float32
 evaluations of the same formula -- torch on the CPU (the oracle: the reference's own arithmetic library) and the HIP kernels --
 differ by ~1e-4 px, so a coordinate that sits within that distance of an integer can truncate differently. This test counts
-those pixels for the three decode kernels and both camera profiles, over the 445 landmarks and over the whole mesh, asserts that
+those pixels for the four decode kernels and both camera profiles, over the 445 landmarks and over the whole mesh, asserts that
 every one of them lies within 1e-3 px of an integer and differs by exactly one, and asks oracle/lbs_independent.py (the SMPL
 paper's formulation in float64) which side truncates like the float64 value. The table goes to gpurun_out/r06_parity_pixels.md
 (committed as profiles/r06_parity_pixels.md)."""
@@ -57,7 +57,7 @@ def test_integer_pixels_at_batch_2048_both_kernels_both_cameras(flame_model, fla
         params = synthetic.synthetic_params(BATCH, seed=2048 + len(profile), profile=profile)
         ref = _oracle_projection(fc, params)                      # float32 [B, V, 2], torch CPU
         ref_px = ref.astype(int)                                  # demo_utils.py:42
-        for kernel in ("pipelined", "two_role", "split_bf16"):
+        for kernel in ("pipelined", "two_role", "split_bf16", "split_f16"):
             hm = HeadMesh(flame_model=flame_model, landmarks=lm, static=static, device=0)
             hm.flame.select_kernel(kernel)
             out = hm.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True, landmarks=False, landmarks_px=True)
@@ -86,11 +86,11 @@ def test_integer_pixels_at_batch_2048_both_kernels_both_cameras(flame_model, fla
                     assert hip_right + cpu_right == len(where)                    # they differ by one: float64 sides with exactly one
                 rate = len(where) / n_px
                 assert rate < 2e-4, (profile, kernel, what, rate)
-                if kernel == "split_bf16" and sel is None:  # the gated mode's own bar, on the large sample (20.6 M pixels)
+                if kernel.startswith("split") and sel is None:  # the gated mode's own bar, on the large sample (20.6 M pixels)
                     assert rate <= 1.5e-5, (profile, what, rate)
                 lines.append(f"| {profile} | {kernel} | {what}: {n_px} | {len(where)} | {rate:.2e} | {far:.2e} | {hip_right} | {cpu_right} |")
             del hm
-    text = ("# Integer-pixel parity at batch 2048 (BASELINE configs[3]), the three decode kernels, both camera profiles\n\n"
+    text = ("# Integer-pixel parity at batch 2048 (BASELINE configs[3]), the four decode kernels, both camera profiles\n\n"
             "Written by tests/test_gpu_parity_pixels.py on the GPU box. `differ` = pixels where `(int)` of the HIP coordinate is not `(int)` of the\n"
             "torch-CPU oracle's (the reference's arithmetic, float32); every one of them is asserted to differ by exactly one and to have a float\n"
             f"coordinate within {NEAR} px of an integer. The last two columns: which side truncates like the float64 evaluation of the same formula\n"

@@ -97,6 +97,32 @@ __global__ void split_gemm(const float* A, const float* B, float* C, Variant v) 
     }
 }
 
+// fp16 x 2: x S = h1 + h2 (+ a remainder <= 2^-23 |x S|), h1 = fp16(x S), h2 = fp16(x S - h1) -- 22 significant bits in two planes;
+// S a power of two per operand (exact; fp16 has 5 exponent bits: the residual of a small basis entry must not underflow), the sum scaled
+// back by 1 / (SA SB). Products: h1g1 | h1g2 + h2g1 | (nprod = 4: h2g2) on v_mfma_f32_16x16x32_f16.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ void f16_gemm(const float* A, const float* B, float* C, int nprod, int two_acc, float sa, float sb) {
+    const int lane = threadIdx.x & 63;
+    const int tm = blockIdx.x / (N / 16), tn = blockIdx.x % (N / 16);
+    const int row = tm * 16 + (lane & 15), col = tn * 16 + (lane & 15), kq = 8 * (lane >> 4);
+    f32x4 hi = {}, lo = {};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        f16x8 a1, a2, b1, b2;
+        for (int i = 0; i < 8; ++i) {
+            const float xa = A[row * K + k0 + kq + i] * sa, xb = B[(k0 + kq + i) * N + col] * sb;
+            a1[i] = (_Float16)xa, a2[i] = (_Float16)(xa - (float)a1[i]);
+            b1[i] = (_Float16)xb, b2[i] = (_Float16)(xb - (float)b1[i]);
+        }
+        if (nprod >= 4) lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, lo, 0, 0, 0);
+        if (two_acc) hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, hi, 0, 0, 0);
+        else lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, lo, 0, 0, 0);
+    }
+    const float inv = 1.0f / (sa * sb);
+    for (int r = 0; r < 4; ++r) C[(tm * 16 + 4 * (lane >> 4) + r) * N + col] = (lo[r] + hi[r]) * inv;
+}
+
 // the product kernel's arithmetic: v_mfma_f32_16x16x4_f32, k ascending, one accumulator
 __global__ void f32_gemm(const float* A, const float* B, float* C) {
     const int lane = threadIdx.x & 63;
@@ -155,6 +181,18 @@ int main() {
             }
         report("host fmaf chain, k ascending", h, ref, mag);
     }
+    for (float sb : {1.0f, 256.0f, 65536.0f})
+        for (float sa : {1.0f, 16.0f})
+            for (int nprod : {3, 4})
+                for (int two_acc : {0, 1}) {
+                    hipMemset(dC, 0, C.size() * 4);
+                    f16_gemm<<<(M / 16) * (N / 16), 64>>>(dA, dB, dC, nprod, two_acc, sa, sb);
+                    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+                    hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
+                    char name[128];
+                    snprintf(name, sizeof name, "fp16x2 16x16x32, A x %g, B x %g, %d products, %d acc", sa, sb, nprod, two_acc + 1);
+                    report(name, C, ref, mag);
+                }
     const char* shape_name[2] = {"16x16x32", "32x32x16"};
     const char* order_name[4] = {"1 acc, small first", "1 acc, big first", "2 acc (a1b1 | rest)", "3 acc by magnitude"};
     for (int trunc = 0; trunc < 2; ++trunc)
