@@ -529,7 +529,9 @@ def secondary_decode_b256(hm, lib, lmk_idx, dev, steps: int = 400, settle: int =
     except Exception as e:
         out["verification"] = {"checked": False, "why": f"{type(e).__name__}: {e}"}
         out["outputs_verified"] = None
-    out["split"] = secondary_decode_b256_split(hm, lib, dev, params, g if out["verification"].get("checked") else None, lmk_idx, stream, steps, settle, t)
+    gold = g if out["verification"].get("checked") else None
+    out["split"] = secondary_decode_b256_split(hm, lib, dev, params, gold, lmk_idx, stream, steps, settle, t)
+    out["split_f16"] = secondary_decode_b256_split(hm, lib, dev, params, gold, lmk_idx, stream, steps, settle, t, form="split_f16")
     # BASELINE configs[3]'s per-GPU work (2048 rows over 8 GPUs = 256 each, only the 445 projected landmarks are gathered): the same rows,
     # landmark outputs only -> the C ABI runs the sub-model of the listed vertices (include/dad3d.h: dad3d_flame_num_landmark_vertices).
     lmk_only = torch.zeros_like(lmk_px)
@@ -573,15 +575,17 @@ def secondary_decode_b256(hm, lib, lmk_idx, dev, steps: int = 400, settle: int =
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline figure is twice this)
 
 
-def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, steps, settle, t_fp32):
-    """The same configs[2] step on the GATED bf16x3 exact-product split of the contraction (csrc/flame_decode_split.hip,
-    dad3d_flame_select_kernel(DAD3D_KERNEL_SPLIT_BF16)): a pre-pass + the tile kernel per step, both inside the timed launches; outputs
-    held to the same goldens and bars as the fp32 leg. Not the default, not the headline: `value` / `dtype` / `roofline` stay on fp32."""
+def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, steps, settle, t_fp32, form="split_bf16"):
+    """The same configs[2] step on a GATED exact-product split of the contraction (csrc/flame_decode_split.hip;
+    dad3d_flame_select_kernel(DAD3D_KERNEL_SPLIT_BF16): three bf16 planes, six products per K = 32; DAD3D_KERNEL_SPLIT_F16: two fp16
+    planes, three products): a pre-pass + the tile kernel per step, both inside the timed launches; outputs held to the same goldens and
+    bars as the fp32 leg. Not the default, not the headline: `value` / `dtype` / `roofline` stay on fp32."""
     from dad_3dheads_amd import _lib
 
     b = params.shape[0]
     twin = hm.fork()
-    twin.flame.select_kernel("split_bf16")
+    twin.flame.select_kernel(form)
+    n_prod, planes = (6, "bf16x3") if form == "split_bf16" else (3, "fp16x2")
     p2 = params.clone()
     verts3d = torch.empty((b, N_VERTS, 3), dtype=torch.float32, device=dev)
     proj3 = torch.empty((b, N_VERTS, 3), dtype=torch.float32, device=dev)
@@ -598,14 +602,16 @@ def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, s
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
     rows16 = (b + 15) // 16 * 16
-    issued = 6 * 2.0 * rows16 * 416 * 64 * ((N_VERTS + 19) // 20)  # six bf16 MFMA products per (row, k, column) of every 64-column tile
+    issued = n_prod * 2.0 * rows16 * 416 * 64 * ((N_VERTS + 19) // 20)  # six (three) MFMA products per (row, k, column) of every 64-column tile
     flops = FLOP_PER_IMAGE * b
-    out = {"workload": "BASELINE configs[2] on the gated bf16x3 split: the same 256 rows and outputs, pre-pass + tile kernel per step",
-           "kernel": "split_params_kernel + flame_decode_split_kernel<false>", "dtype": "bf16x3 exact-product split, fp32 accumulate",
+    out = {"workload": f"BASELINE configs[2] on the gated {planes} split: the same 256 rows and outputs, pre-pass + tile kernel per step",
+           "kernel": f"split_params_kernel<{planes}> + flame_decode_split_kernel<{planes}, false>",
+           "dtype": f"{planes} exact-product split ({n_prod} products per K = 32), fp32 accumulate",
            "steps": steps, "settle_passes": passes, "ms_per_step": t * 1e3, "images_per_sec": b / t, "speedup_vs_fp32_leg": t_fp32 / t,
            "issued_bf16_flop_per_step": issued, "frac_bf16": issued / t / 1e12 / PEAK_BF16_MFMA_TFLOPS, "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+           "peak_note": "dense 16-bit matrix peak: the same for bf16 and fp16 operands",
            "fp32_equivalent_TFLOPs": flops / t / 1e12, "fp32_equivalent_frac_of_fp32_mfma_peak": flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-           "error_vs_float64": "profiles/r06_split_error.md (2-3x closer than the fp32 kernel on every line)"}
+           "error_vs_float64": "profiles/r06_split_error.md (both forms ~2x closer than the fp32 kernel on every 3-D line)"}
     if golden is not None:
         sub = torch.from_numpy(golden["subset"]).to(dev)
         dv = float(np.abs(verts3d[:, sub].cpu().numpy() - golden["v3d_sub"]).max())
@@ -967,8 +973,10 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         except Exception as e:  # the metric's line must not depend on the CNN stack
             out["secondary"]["e2e_b64"] = {"error": f"{type(e).__name__}: {e}"}
         out["secondary"]["decode_b256_split"] = out["secondary"]["decode_b256"].pop("split")
+        out["secondary"]["decode_b256_split_f16"] = out["secondary"]["decode_b256"].pop("split_f16")
         out["secondary"]["outputs_verified"] = bool(out["secondary"]["decode_b256"]["outputs_verified"]) and \
             bool(out["secondary"]["decode_b256_split"].get("outputs_verified")) and \
+            bool(out["secondary"]["decode_b256_split_f16"].get("outputs_verified")) and \
             bool(out["secondary"]["decode_b256"]["landmarks_only"]["outputs_verified"]) and \
             bool(render["timed_images_match_reference_raster"]) and bool(out["config"]["outputs_verified"])
     return out

@@ -84,6 +84,7 @@ struct Bf16x3 {
     static constexpr int PLN = kSplitPlaneBytes;       // the planes of a phase [NPL][16 rows][RS], padded to a multiple of 1 KB
     static constexpr float kScaleA = 1.0f;
     static constexpr bool kScaled = false;
+    static constexpr int kFinishers = 3;               // 8 waves of up to 256 registers: calls j and j + 3 per finisher and window
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 struct F16x2 {
@@ -93,6 +94,8 @@ struct F16x2 {
     static constexpr int PLN = (2 * kSplitRows * kSplitRowBytes + 1023) / 1024 * 1024;
     static constexpr float kScaleA = 16.0f;            // params rows x 16: residuals of |x| >= 2^-7 stay normal, |x| up to 4094 representable
     static constexpr bool kScaled = true;
+    static constexpr int kFinishers = 5;               // the basis slice is 104 registers here, the kernel fits 168: TEN waves (three per SIMD
+                                                       // on two of them), one finishing call per finisher and window instead of two
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 static_assert(Bf16x3::PLN + CST == kSplitBlockBytes && F16x2::PLN <= Bf16x3::PLN, "the scratch is sized for the larger form");
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
 // long as a window). Finishers, window p: tile p - 2 out of tile pair p & 1 (parked behind B(p - 2), visible behind B(p - 1); written
 // next behind B(p)), constants from ring slot (p - 2) & 7 (written next in window p + 4).
 template <class S, bool TO2D>
-__global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a) {
+__global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) / 4) void flame_decode_split_kernel(SplitArgs a) {
     typedef typename S::vec8 vec8;
     constexpr int NPL = S::NPL, PLN = S::PLN, BLK = S::PLN + CST;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -351,11 +354,12 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
         // (measured 1-2 % of a launch at 1024 / 2048 images, priorities 1 and 3 alike)
         __builtin_amdgcn_s_setprio(DAD3D_SPLIT_FIN_PRIO);
         phase_barrier();  // S0
-        const Geo ga = make_geo(fj), gb = make_geo(fj < 2 ? fj + 3 : fj);
+        constexpr bool kTwoCalls = S::kFinishers == 3;  // (five finishers: call fj each)
+        const Geo ga = make_geo(fj), gb = make_geo(kTwoCalls && fj < 2 ? fj + 3 : fj);
 #pragma unroll 1
         for (int p = 0; p < NP; ++p) {
             if (p >= 2 && !(DAD3D_SPLIT_ABLATE & 1)) {
-                if (fj < 2) finish_two(p - 2, ga, gb);
+                if (kTwoCalls && fj < 2) finish_two(p - 2, ga, gb);
                 else finish_one(p - 2, ga);
             }
             phase_barrier();  // B(p)
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void flame_decode_split_kernel(SplitArgs a)
 #pragma unroll 1
     for (int p = 1; p < NP; ++p) phase(p, std::false_type{});
     // the drain: this wave's share of the last two tiles (the basis registers are dead). Tile NP - 2 has been visible since B(NP - 1)
-    if (wave < 2 && !(DAD3D_SPLIT_ABLATE & 1)) {
+    if (S::kFinishers == 3 && wave < 2 && !(DAD3D_SPLIT_ABLATE & 1)) {
         const Geo g = make_geo(3 + wave);
         if (NP >= 2) finish_one(NP - 2, g);
         phase_barrier();  // E
@@ -525,8 +529,8 @@ dad3d_status launch_split(const SplitArgs& a, hipStream_t s, PerDeviceOnce& attr
         attr_done.set(dev);
     }
     hipLaunchKernelGGL(split_params_kernel<S>, dim3(a.n_phase * kSplitRows), dim3(256), 0, s, a);
-    if ((a.flags & DAD3D_TO_2D) || !a.proj) hipLaunchKernelGGL((flame_decode_split_kernel<S, true>), dim3(a.n_tiles), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((flame_decode_split_kernel<S, false>), dim3(a.n_tiles), dim3(512), lds, s, a);
+    if ((a.flags & DAD3D_TO_2D) || !a.proj) hipLaunchKernelGGL((flame_decode_split_kernel<S, true>), dim3(a.n_tiles), dim3(64 * (5 + S::kFinishers)), lds, s, a);
+    else hipLaunchKernelGGL((flame_decode_split_kernel<S, false>), dim3(a.n_tiles), dim3(64 * (5 + S::kFinishers)), lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

@@ -304,6 +304,10 @@ def test_driver_command_carries_the_secondary_legs():
     sp = d["secondary"]["decode_b256_split"]  # the gated bf16x3 split: same rows, same goldens, its own fractions; never the headline
     assert sp["outputs_verified"] is True and sp["dtype"].startswith("bf16x3") and 0 < sp["frac_bf16"] < 1 and sp["fp32_equivalent_TFLOPs"] > 0
     assert d["dtype"] == "f32" and "split" not in d["roofline"]["kernel"]
+    sf = d["secondary"]["decode_b256_split_f16"]  # its second form: two fp16 planes, three products
+    assert sf.get("outputs_verified") is True, sf
+    assert sf["verification"]["max_abs_3d"] < 5e-6 and sf["verification"]["max_abs_px"] < 1e-3 and sf["verification"]["landmark_gather_exact"]
+    assert sf["ms_per_step"] < 0.030, sf  # measured 0.020-0.021 (the bf16 form 0.025, the fp32 leg 0.038)
     e2e = d["secondary"]["e2e_b64"]  # the north star's sentence, reported separately from the metric
     assert "error" not in e2e, e2e
     assert e2e["gpu_outputs_finite"] is True and e2e["cpu_reference_predictor"]["threads"] == 8 and e2e["ratio"] > 0 and e2e["north_star_target_ratio"] == 200
