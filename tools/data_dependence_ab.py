@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostics: does a decode launch's time depend on the VALUES of params? us/launch at the batch sizes given with synthetic rows,
-all-zero rows, and rows of 4x the usual magnitude -- kernel from DAD3D_DECODE_KERNEL.
+all-zero rows, and rows of 4x the usual magnitude -- kernel from DAD3D_DECODE_KERNEL (split | split_f16 | unset).
 
     [DAD3D_DECODE_KERNEL=split] python tools/data_dependence_ab.py 256 2048"""
 import os

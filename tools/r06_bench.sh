@@ -12,6 +12,7 @@ print("toolchain", d["config"]["toolchain"]); print("note", d["config"]["scaling
 s = d["secondary"]
 print("b256", s["decode_b256"]["ms_per_step"], s["decode_b256"]["frac"], s["decode_b256"]["outputs_verified"])
 print("split", json.dumps(s["decode_b256_split"]))
+print("split_f16", json.dumps(s["decode_b256_split_f16"]))
 print("lmk", json.dumps(s["decode_b256"]["landmarks_only"]))
 print("e2e", json.dumps(s["e2e_b64"]))
 print("verified", s["outputs_verified"], "render", s["render_b64"]["us_per_batch"])

@@ -15,8 +15,11 @@ from collections import defaultdict
 
 
 def short(name):
+    if "flame_decode_split_kernel" in name or "split_params_kernel" in name:  # templates over the split form (Bf16x3 | F16x2)
+        form = "F16x2" if "F16x2" in name else "Bf16x3"
+        return ("split_params_kernel" if "split_params" in name else "flame_decode_split_kernel") + f"<{form}>"
     for key in ("flame_decode_pipe_kernel<true, false>", "flame_decode_pipe_kernel<false, false>", "flame_decode_pipe_kernel<true, true>",
-                "flame_decode_split_kernel<false>", "flame_decode_split_kernel<true>", "split_params_kernel", "flame_decode_kernel", "raster_kernel<0>", "raster_blend_kernel",
+                "flame_decode_kernel", "raster_kernel<0>", "raster_blend_kernel",
                 "tri_geometry_kernel<true, 2>", "tri_geometry_kernel<true, 0>", "readjust_kernel", "ncclDevKernel", "copyBuffer", "fillBuffer"):
         if key in name:
             return key
@@ -65,14 +68,15 @@ def main():
 
 
 def split_lines(dur, bench):
-    sp = dur.get("flame_decode_split_kernel<false>", [])
-    pre = dur.get("split_params_kernel", [])
-    if sp and bench and "decode_b256_split" in bench.get("secondary", {}):
-        leg = bench["secondary"]["decode_b256_split"]
-        steps = int(leg["steps"])
-        a, b = sum(sp[-steps:]) / steps, sum(pre[-steps:]) / max(len(pre[-steps:]), 1)
-        print(f"bf16x3 split, B = 256: tile kernel {a:.3f} us + pre-pass {b:.3f} us = {a + b:.3f} us per step over the timed pass (the last {steps} launches); "
-              f"the same run printed secondary.decode_b256_split.ms_per_step {leg['ms_per_step'] * 1e3:.3f} us (the difference is the gap between the two launches)")
+    for form, legname, what in (("Bf16x3", "decode_b256_split", "bf16x3 split"), ("F16x2", "decode_b256_split_f16", "fp16x2 split")):
+        sp = dur.get(f"flame_decode_split_kernel<{form}>", [])
+        pre = dur.get(f"split_params_kernel<{form}>", [])
+        if sp and bench and legname in bench.get("secondary", {}):
+            leg = bench["secondary"][legname]
+            steps = int(leg["steps"])
+            a, b = sum(sp[-steps:]) / steps, sum(pre[-steps:]) / max(len(pre[-steps:]), 1)
+            print(f"{what}, B = 256: tile kernel {a:.3f} us + pre-pass {b:.3f} us = {a + b:.3f} us per step over the timed pass (the last {steps} launches); "
+                  f"the same run printed secondary.{legname}.ms_per_step {leg['ms_per_step'] * 1e3:.3f} us (the difference is the gap between the two launches)")
     lm = dur.get("flame_decode_pipe_kernel<true, true>", [])
     if lm:
         print(f"landmark sub-model (chunked grid): {len(lm)} launches, B = 256 and B = 2048 legs together; min {min(lm):.2f} us, max {max(lm):.2f} us")

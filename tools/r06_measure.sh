@@ -13,7 +13,7 @@ python "$root/tools/r06_kernel_summary.py" /tmp/prof_bench "$out/bench_profiled.
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  for k in split fp32; do
+  for k in split split_f16 fp32; do
     rm -rf /tmp/pmcs_${k}_$i
     (cd /tmp && timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcs_${k}_$i -- python $root/tools/split_pmc_driver.py $k 256 120 > /dev/null 2>/tmp/pmcs_err)
     f=$(find /tmp/pmcs_${k}_$i -name "*counter_collection.csv" | head -1)
@@ -24,14 +24,14 @@ python3 - "$out" <<'PY'
 import collections, csv, glob, json, sys
 res = {"method": "tools/r06_measure.sh: rocprofv3 --pmc <one set per pass> --kernel-trace over tools/split_pmc_driver.py (B = 256, every output, 120 launches; "
                  "mean per launch over the last 100); FETCH_SIZE / WRITE_SIZE in KB, fetch bytes = 2 x FETCH_SIZE x 1024 on gfx950 (MI355X_MICROARCH.md)", "kernels": {}}
-for k in ("split", "fp32"):
+for k in ("split", "split_f16", "fp32"):
     acc, dur = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(list)
     for path in sorted(glob.glob(f"/tmp/pmcs_{k}_set*.csv")):
         for r in csv.DictReader(open(path)):
             n = r["Kernel_Name"]
             if "flame_decode" not in n and "split_params" not in n:
                 continue
-            short = n.split("(")[0].replace("void dad3d::", "")
+            short = n[:n.rfind("(")].replace("void dad3d::", "").replace("dad3d::", "").replace("(anonymous namespace)::", "")
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[short].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
     for short, cs in acc.items():
@@ -43,6 +43,6 @@ for k in ("split", "fp32"):
             e["traffic_bytes_per_launch"] = 2 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024
         res["kernels"][short] = e
 json.dump(res, open(sys.argv[1] + "/pmc_split_b256.json", "w"), indent=1)
-print(json.dumps(res, indent=1)[:3500])
+print(json.dumps(res, indent=1)[:6000])
 PY
 PMC_OUT=$out/pmc_decode bash $root/tools/pmc_decode.sh > $out/pmc_decode.log 2>&1; tail -25 $out/pmc_decode.log

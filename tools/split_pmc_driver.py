@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics: N launches of the decode at one batch size on the kernel named (fp32 | split), every output -- the workload of the PMC passes
+"""Diagnostics: N launches of the decode at one batch size on the kernel named (fp32 | split | split_f16), every output -- the workload of the PMC passes
 of tools/r06_measure.sh (rocprofv3 --pmc ... -- python tools/split_pmc_driver.py split 256 200)."""
 import os, sys
 import torch
@@ -10,7 +10,7 @@ from dad_3dheads_amd.head_mesh import HeadMesh  # noqa: E402
 kernel, b, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 st = synthetic.load_static()
 hm = HeadMesh(flame_model=synthetic.synthetic_flame_model(0, st), landmarks=landmarks.canonical("445", st), static=st, device=0)
-hm.flame.select_kernel("split_bf16" if kernel == "split" else "pipelined")
+hm.flame.select_kernel({"split": "split_bf16", "split_f16": "split_f16"}.get(kernel, "pipelined"))
 lib = _lib.load()
 p = torch.from_numpy(synthetic.synthetic_params(b, seed=b)).cuda()
 v3 = torch.empty((b, 5023, 3), device="cuda"); pr = torch.empty((b, 5023, 3), device="cuda")
