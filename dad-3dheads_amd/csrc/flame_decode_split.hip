@@ -173,20 +173,26 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
         const int pl = (t - 208) >> 2, w = (t - 208) & 3;
         *reinterpret_cast<unsigned*>(row + (size_t)pl * QB * RS + 832 + 4 * w) = 0u;
     } else if (t == 255 && !(DAD3D_SPLIT_ABLATE & 8192)) {  // (8192: real planes, constants left zero)
+        float* c = reinterpret_cast<float*>(blk + PLN + (size_t)(b % QB) * 96);
+        *reinterpret_cast<float4*>(c) = float4{D[0], D[1], D[2], D[3]};
+        *reinterpret_cast<float4*>(c + 4) = float4{D[4], D[5], D[6], D[7]};
+        c[8] = D[8];
+    }
+    // the other half of the constants on the FIRST wave (thread 0, beside its pair of betas): the 6-DoF rotation's chain runs while the last
+    // wave is in the jaw's sine / cosine -- one thread for both was the pre-pass's critical path
+    if (t == 0 && !(DAD3D_SPLIT_ABLATE & 8192)) {
         const float rot6[6] = {prow[403], prow[404], prow[405], prow[406], prow[407], prow[408]};
+        const float sp1 = prow[412] + 1.0f, tx = prow[409], ty = prow[410];
         float G[9];
         rot6_to_matrix_lean(rot6, G);
-        const float sp1 = prow[412] + 1.0f;
         const float s = sp1 < 1e-8f ? 1e-8f : sp1;  // head_mesh.py:39 torch.clamp(min=): a NaN scale stays NaN
-        float4* c = reinterpret_cast<float4*>(blk + PLN + (size_t)(b % QB) * 96);
-        c[0] = float4{D[0], D[1], D[2], D[3]};
-        c[1] = float4{D[4], D[5], D[6], D[7]};
-        c[2] = float4{D[8], G[0], G[1], G[2]};
-        c[3] = float4{G[3], G[4], G[5], G[6]};
+        float* c = reinterpret_cast<float*>(blk + PLN + (size_t)(b % QB) * 96);
+        c[9] = G[0], c[10] = G[1], c[11] = G[2];
+        *reinterpret_cast<float4*>(c + 12) = float4{G[3], G[4], G[5], G[6]};
         // head_mesh.py:39-43 ((v s + t) + 1) / 2 * image_size as ONE fma per component in the finishers: v (s h) + (t + 1) h, h = image_size / 2
         const float hh = a.image_size * 0.5f;
-        c[4] = float4{G[7], G[8], s * hh, (prow[409] + 1.0f) * hh};
-        c[5] = float4{(prow[410] + 1.0f) * hh, hh, 0.f, 0.f};
+        *reinterpret_cast<float4*>(c + 16) = float4{G[7], G[8], s * hh, (tx + 1.0f) * hh};
+        *reinterpret_cast<float4*>(c + 20) = float4{(ty + 1.0f) * hh, hh, 0.f, 0.f};
         if ((a.flags & DAD3D_MUTATE_PARAMS) && live) prow[kNumBeta + 11] = 0.0f;  // translation z := 0 (head_mesh.py:41)
     }
 }

@@ -58,3 +58,24 @@ def test_no_scratch_no_vgpr_spills(source, flags, sgpr_ok, vgpr_cap, tmp_path):
     hot = max(int(k["VGPRs"]) for k in kernels.values())
     assert hot <= vgpr_cap, (source, hot)
     print(source, {n[-60:]: (k["VGPRs"], k["SGPRs Spill"]) for n, k in kernels.items()})
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_split_kernels_register_budgets_and_no_packed_f32(tmp_path):
+    """The fp16x2 form launches TEN waves per workgroup (three per SIMD on two of them): 512 / 3 -> at most 168 registers, without spills; the
+    bf16x3 form eight (256). Neither may contain a packed-f32 VALU instruction: `v_pk_*_f32` in a wave beside a 16-bit MFMA stream returned wrong
+    low halves (profiles/r06_kernel_log.md section 4) -- the file is built with -fno-slp-vectorize and scales its vectors element by element."""
+    kernels = _resource_usage("flame_decode_split.hip", ["-fno-slp-vectorize"], tmp_path)
+    f16 = {n: k for n, k in kernels.items() if "flame_decode_split_kernel" in n and "F16x2" in n}
+    bf16 = {n: k for n, k in kernels.items() if "flame_decode_split_kernel" in n and "Bf16x3" in n}
+    assert len(f16) == 2 and len(bf16) == 2, list(kernels)
+    for name, k in f16.items():
+        assert int(k["VGPRs"]) + int(k.get("AGPRs", 0)) <= 168 and int(k["Occupancy"]) >= 3, (name, k)
+    for name, k in bf16.items():
+        assert int(k["VGPRs"]) + int(k.get("AGPRs", 0)) <= 256 and int(k["Occupancy"]) >= 2, (name, k)
+    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-fno-slp-vectorize", "-S",
+                          os.path.join(CSRC, "flame_decode_split.hip"), "-o", "-"], capture_output=True, text=True, cwd=CSRC)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    packed = sorted(set(re.findall(r"\bv_pk_\w*f32\b", asm.stdout)))
+    assert not packed, packed
+    assert asm.stdout.count("v_mfma_f32_16x16x32_f16") > 0 and asm.stdout.count("v_mfma_f32_16x16x32_bf16") > 0
