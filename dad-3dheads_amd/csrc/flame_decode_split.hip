@@ -85,6 +85,7 @@ struct Bf16x3 {
     static constexpr float kScaleA = 1.0f;
     static constexpr bool kScaled = false;
     static constexpr int kFinishers = 3;               // 8 waves of up to 256 registers: calls j and j + 3 per finisher and window
+    static constexpr int kWriteBackFrom = 1024;        // batch size from which the vertex stores are write-back (measured crossover)
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 struct F16x2 {
@@ -94,6 +95,7 @@ struct F16x2 {
     static constexpr int PLN = (2 * kSplitRows * kSplitRowBytes + 1023) / 1024 * 1024;
     static constexpr float kScaleA = 16.0f;            // params rows x 16: residuals of |x| >= 2^-7 stay normal, |x| up to 4094 representable
     static constexpr bool kScaled = true;
+    static constexpr int kWriteBackFrom = 640;
     static constexpr int kFinishers = 5;               // the basis slice is 104 registers here, the kernel fits 168: TEN waves (three per SIMD
                                                        // on two of them), one finishing call per finisher and window instead of two
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -207,7 +209,10 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
 // constants into ring slot (p + 2) & 7, then waits for phase p + 1's (requested a window earlier: a global -> LDS round trip is as
 // long as a window). Finishers, window p: tile p - 2 out of tile pair p & 1 (parked behind B(p - 2), visible behind B(p - 1); written
 // next behind B(p)), constants from ring slot (p - 2) & 7 (written next in window p + 4).
-template <class S, bool TO2D>
+// WB: the vertex stores write-back (L2 merges the seams, one write per line to HBM) instead of write-through: 3-6 % faster from ~600 (fp16x2) /
+// ~1000 (bf16x3) images up -- these kernels are energy-bound there -- and 10 % SLOWER at 256 (the dirty lines leave at the end of the launch);
+// the launcher chooses by batch size, the bits are the same.
+template <class S, bool TO2D, bool WB>
 __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) / 4) void flame_decode_split_kernel(SplitArgs a) {
     typedef typename S::vec8 vec8;
     constexpr int NPL = S::NPL, PLN = S::PLN, BLK = S::PLN + CST;
@@ -219,7 +224,11 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the roles branch and loop on SGPRs, not under exec masks
-    const int tile = blockIdx.x, v0 = tile * TV;
+    // Block b runs on XCD b % 8 (observed, for speed only): an XCD gets a CONTIGUOUS run of tiles, so that the partial cache lines at the
+    // seams of neighbouring tiles' stores (runs of 240 / 160 bytes at 4-byte alignment) meet in ONE L2 when the stores are write-back (WB)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nt = a.n_tiles, big = nt & 7, per = nt >> 3;  // the first `big` XCDs hold per + 1 tiles
+    const int tile = xcd < big ? xcd * (per + 1) + slot : big * (per + 1) + (xcd - big) * per + slot;
+    const int v0 = tile * TV;
     const int NP = a.n_phase, B = a.batch;
 
     if (wave == 4) {
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
         const int b = q * QB + g.i;
         const bool live = b < B && g.vlive && !((DAD3D_SPLIT_ABLATE & 256) && o.ox != 12345.678f);
         const unsigned row0 = (unsigned)(q * QB) * (unsigned)a.n_verts;  // (scalar)
-        vertex_store_at<TO2D>(cx, rs3, rsp, o, __float_as_int(g.vt.z), __float_as_int(g.vt.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
+        vertex_store_at<TO2D, WB ? 0 : DAD3D_PIPE_STORE_AUX>(cx, rs3, rsp, o, __float_as_int(g.vt.z), __float_as_int(g.vt.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
                               live && nl > 0 && __float_as_int(g.vt.z) >= 0, g.off3 + row0 * 12u, g.offp + row0 * kPB, (unsigned)b * nl);
     };
     auto finish_one = [&](int q, const Geo& g) {
@@ -529,14 +538,20 @@ dad3d_status launch_split(const SplitArgs& a, hipStream_t s, PerDeviceOnce& attr
     const int dev = PerDeviceOnce::current();
     const size_t lds = (size_t)Lds<S>::total;
     if (!attr_done.done(dev)) {
-        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_split_kernel<S, true>),
-                              reinterpret_cast<const void*>(&flame_decode_split_kernel<S, false>)})
+        for (const void* k : {reinterpret_cast<const void*>(&flame_decode_split_kernel<S, true, false>),
+                              reinterpret_cast<const void*>(&flame_decode_split_kernel<S, false, false>),
+                              reinterpret_cast<const void*>(&flame_decode_split_kernel<S, true, true>),
+                              reinterpret_cast<const void*>(&flame_decode_split_kernel<S, false, true>)})
             DAD3D_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done.set(dev);
     }
     hipLaunchKernelGGL(split_params_kernel<S>, dim3(a.n_phase * kSplitRows), dim3(256), 0, s, a);
-    if ((a.flags & DAD3D_TO_2D) || !a.proj) hipLaunchKernelGGL((flame_decode_split_kernel<S, true>), dim3(a.n_tiles), dim3(64 * (5 + S::kFinishers)), lds, s, a);
-    else hipLaunchKernelGGL((flame_decode_split_kernel<S, false>), dim3(a.n_tiles), dim3(64 * (5 + S::kFinishers)), lds, s, a);
+    const bool to2d = (a.flags & DAD3D_TO_2D) || !a.proj, wb = a.batch >= S::kWriteBackFrom;
+    const dim3 grid(a.n_tiles), block(64 * (5 + S::kFinishers));
+    if (to2d && wb) hipLaunchKernelGGL((flame_decode_split_kernel<S, true, true>), grid, block, lds, s, a);
+    else if (to2d) hipLaunchKernelGGL((flame_decode_split_kernel<S, true, false>), grid, block, lds, s, a);
+    else if (wb) hipLaunchKernelGGL((flame_decode_split_kernel<S, false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((flame_decode_split_kernel<S, false, false>), grid, block, lds, s, a);
     DAD3D_HIP_TRY(hipGetLastError());
     return DAD3D_OK;
 }

@@ -116,14 +116,15 @@ __device__ __forceinline__ void vertex_store(const EpiCtx& cx, __amdgpu_buffer_r
     }
 }
 
-// vertex_store with the byte offsets of the vertex given (the split kernel keeps them per lane across phases)
-template <bool TO2D>
+// vertex_store with the byte offsets of the vertex given (the split kernel keeps them per lane across phases) and the cache policy of the
+// vertex stores as a parameter (16 = sc1 write-through, 0 = write-back)
+template <bool TO2D, int AUX = DAD3D_PIPE_STORE_AUX>
 __device__ __forceinline__ void vertex_store_at(const EpiCtx& cx, __amdgpu_buffer_rsrc_t rs3, __amdgpu_buffer_rsrc_t rsp, const VertexOut& o, int lh, int ln, bool st3,
                                                 bool stp, bool stl, unsigned off3, unsigned offp, unsigned bnl) {
-    if (st3) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.rx, o.ry, o.rz}), rs3, (int)off3, 0, DAD3D_PIPE_STORE_AUX);
+    if (st3) __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.rx, o.ry, o.rz}), rs3, (int)off3, 0, AUX);
     if (stp) {
-        if (TO2D) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{o.ox, o.oy}), rsp, (int)offp, 0, DAD3D_PIPE_STORE_AUX);
-        else __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.ox, o.oy, o.oz}), rsp, (int)offp, 0, DAD3D_PIPE_STORE_AUX);
+        if (TO2D) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f2u{o.ox, o.oy}), rsp, (int)offp, 0, AUX);
+        else __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, f3u{o.ox, o.oy, o.oz}), rsp, (int)offp, 0, AUX);
     }
     if (stl) {
         auto put = [&](int slot) {

@@ -139,7 +139,7 @@ def test_split_kernel_matches_reference_goldens(meshes, decode_golden, static):
 
 
 # ragged and aligned batch sizes around every boundary of the 16-image phases
-@pytest.mark.parametrize("batch", [1, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 100, 128, 129, 259, 385])
+@pytest.mark.parametrize("batch", [1, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 100, 128, 129, 259, 385, 641, 1030])
 @pytest.mark.parametrize("to_2d", [True, False])
 def test_split_kernel_matches_oracle_and_the_fp32_kernel(meshes, flame_consts, static, batch, to_2d):
     split, pipe = meshes
@@ -270,3 +270,15 @@ def test_split_kernel_two_forks_on_two_streams(meshes):
     for oa, ob in outs:
         for k in ("verts3d", "proj", "lmk_xy"):
             assert torch.equal(oa[k], want_a[k]) and torch.equal(ob[k], want_b[k]), k
+
+
+def test_write_back_and_write_through_launches_return_the_same_bits(meshes):
+    """From 640 (fp16x2) / 1024 (bf16x3) images up the tile kernel's vertex stores are write-back instead of write-through (a cache policy:
+    csrc/flame_decode_split.hip, WB): the first 100 rows of a launch of 1100, decoded again on their own, come back bit for bit."""
+    split, _ = meshes
+    params = synthetic.synthetic_params(1100, seed=6700)
+    big = split.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True, landmarks=True, landmarks_px=True)
+    small = split.decode(torch.from_numpy(params[:100].copy()).cuda(), to_2d=True, landmarks=True, landmarks_px=True)
+    torch.cuda.synchronize()
+    for k in ("verts3d", "proj", "lmk_xy", "lmk_px"):
+        assert torch.equal(big[k][:100], small[k]), k

@@ -68,7 +68,7 @@ def test_split_kernels_register_budgets_and_no_packed_f32(tmp_path):
     kernels = _resource_usage("flame_decode_split.hip", ["-fno-slp-vectorize"], tmp_path)
     f16 = {n: k for n, k in kernels.items() if "flame_decode_split_kernel" in n and "F16x2" in n}
     bf16 = {n: k for n, k in kernels.items() if "flame_decode_split_kernel" in n and "Bf16x3" in n}
-    assert len(f16) == 2 and len(bf16) == 2, list(kernels)
+    assert len(f16) == 4 and len(bf16) == 4, list(kernels)  # TO2D x write-back / write-through stores
     for name, k in f16.items():
         assert int(k["VGPRs"]) + int(k.get("AGPRs", 0)) <= 168 and int(k["Occupancy"]) >= 3, (name, k)
     for name, k in bf16.items():
