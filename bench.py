@@ -454,7 +454,14 @@ def decode_kernel_label():
     env = os.environ.get("DAD3D_DECODE_KERNEL", "")
     if env.startswith("v1"):
         return "flame_decode_kernel (two-role kernel of rounds 1-3, forced by DAD3D_DECODE_KERNEL=v1)"
+    if env in ("split", "split_f16"):
+        return f"split_params_kernel + flame_decode_split_kernel ({'bf16x3' if env == 'split' else 'fp16x2'} split, forced by DAD3D_DECODE_KERNEL={env})"
     return "flame_decode_pipe_kernel<true> (single role, persistent tiles, one launch per step)"
+
+
+def decode_dtype_label():
+    """`dtype` of the line: the arithmetic the contraction runs in -- f32 unless the environment forces a gated split form (never the driver's run)."""
+    return {"split": "bf16x3 split, f32 accumulate", "split_f16": "f16x2 split, f32 accumulate"}.get(os.environ.get("DAD3D_DECODE_KERNEL", ""), "f32")
 
 
 def events_per_step(fn, steps: int, stream, dev, warmup: int = 0, settle: int = 0):
@@ -892,7 +899,7 @@ def run_decode(args, dist, dev, rank, world, hm, lib, static, model, lmk_idx):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": decode_dtype_label(),
         "data": "synthetic",
         "config": {
             "value_definition": ("images / ms_per_step_with_gather (process group: the job ends behind its one all-gather)" if region_s is not None

@@ -2,7 +2,7 @@
 # Round 6: kernel durations (rocprofv3 --kernel-trace --stats) of the split mode's two kernels at the batch sizes given, product and variants.
 export TMPDIR=/tmp
 root="${GRAFT_REPO_ROOT:-/root/repo}"; out="$root/gpurun_out/r06/split_trace"; mkdir -p "$out"; cd /tmp
-export DAD3D_DECODE_KERNEL=split
+export DAD3D_DECODE_KERNEL="${SPLIT_FORM:-split}"
 sizes="$1"; shift
 for v in product "$@"; do
   if [ "$v" = product ]; then unset DAD3D_LIB_PATH; else export DAD3D_LIB_PATH="$root/tools/_variants/lib_$v.so"; fi
