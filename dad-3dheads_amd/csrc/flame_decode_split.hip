@@ -1,5 +1,6 @@
-// FLAME / HeadMesh decode for gfx950 (MI355X), round 6: the blend-shape contraction on the BF16 matrix pipe as an exact-product split.
-// A gated mode (dad3d_flame_select_kernel(DAD3D_KERNEL_SPLIT_BF16) / DAD3D_DECODE_KERNEL=split); the default stays the fp32 kernel.
+// FLAME / HeadMesh decode for gfx950 (MI355X), round 6: the blend-shape contraction on the 16-BIT matrix pipe as an exact-product split.
+// Gated modes (dad3d_flame_select_kernel(DAD3D_KERNEL_SPLIT_BF16 | DAD3D_KERNEL_SPLIT_F16) / DAD3D_DECODE_KERNEL=split | split_f16); the default
+// stays the fp32 kernel. The text below describes the bf16 form first; the fp16 form -- the faster of the two -- follows under "Two forms".
 //
 // Why: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (157 TFLOP/s) -- 8 x 32 cycles per K = 32 of a 16 x 16 tile -- and every VALU
 // instruction beside it costs it ~6 cycles (flame_decode_pipe.hip). The bf16 pipe is 16x faster per instruction and co-issues: measured
@@ -18,14 +19,15 @@
 //     kernel, and performs the tz := 0 side effect. In the fp32 kernel every one of the 252 workgroups recomputes the constants and would
 //     have to re-split the rows: 5.5 VALU instructions per element x 252.
 //   * tile kernel: one workgroup per tile of 20 vertices (the pipelined kernel's pack, read as it is: no second copy of the basis in HBM,
-//     no extra byte in the start-up stream), 8 waves in THREE roles:
+//     no extra byte in the start-up stream; an XCD holds a contiguous run of tiles), 8 (fp16 form: 10) waves in THREE roles:
 //       - four mma waves, each HALF of K x HALF of the columns (78 MFMAs and 21 fragment reads of 1 KB per phase: with every wave on all
 //         of K for 16 columns the LDS pipe, not the matrix pipe, was the bound), their basis slice split into planes ON ARRIVAL and
 //         register-resident for the launch (156 registers). Their one barrier per phase sits between the last fragment read of the phase
 //         and its last six MFMAs: the next phase's first fragments are in flight while those run, and nothing drains.
 //       - one stager wave: global_load_lds (no registers, no ds_write pass) of the next phase's planes + constants, one window ahead.
-//       - three finisher waves: skinning, rotation, projection, landmark slots, stores of the phase before the last (flame_pipe_epilogue.hpp,
-//         shared with the fp32 kernel), every operand from LDS, lanes = consecutive (image, vertex) pairs.
+//       - three (five) finisher waves: skinning, rotation, projection, landmark slots, stores of the phase before the last
+//         (flame_pipe_epilogue.hpp, shared with the fp32 kernel), every operand from LDS, lanes = consecutive (image, vertex) pairs; vertex
+//         stores write-through, write-back at large batches (WB below).
 //   * the k order inside an MFMA is the pack's: lane (q, n) of group g holds k = 32 g + 16 h + 4 q + i (h = 0, 1; i = 0..3), so the
 //     pre-pass stores a row's element k at position 32 g + 8 q + 4 h + i and both operands are one aligned 16-byte read per lane.
 //
