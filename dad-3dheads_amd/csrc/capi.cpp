@@ -617,6 +617,24 @@ static uint64_t trace_entries_two_role(const dad3d_flame* h, int batch) {
 }
 static uint64_t trace_entries_pipe(const dad3d_flame* h) { return (uint64_t)h->c->n_tiles_pipe * 8 * 32; }
 
+// Scratch of the split kernels (pre-pass -> tile kernel): n_phase blocks of kSplitBlockBytes, grown on demand -- never inside a capture.
+static dad3d_status ensure_split_scratch(dad3d_flame* h, int n_phase, hipStream_t s) {
+    if (n_phase <= h->split_cap) return DAD3D_OK;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
+    DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone,
+                  "the first split-kernel decode of a handle (and the first at a larger batch) allocates: run it once before capturing a graph");
+    DAD3D_HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(h->d_split_a);
+    h->d_split_a = nullptr, h->split_cap = 0;
+    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitBlockBytes));
+    // (the padding is copied into LDS, never read.) On the LAUNCH's stream: hipMemset is ordered on the null stream only, and a
+    // non-blocking stream's pre-pass overtook it -- zero planes under the first launch of a fork (found by the two-streams test)
+    DAD3D_HIP_TRY(hipMemsetAsync(h->d_split_a, 0, (size_t)n_phase * kSplitBlockBytes, s));
+    h->split_cap = n_phase;
+    return DAD3D_OK;
+}
+
 static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsigned flags, float* verts3d, float* proj,
                                 float* lmk_xy, int32_t* lmk_px, float* posed, void* stream) {
     DAD3D_REQUIRE(h, "dad3d_flame_decode: null handle");
@@ -630,11 +648,23 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Landmark outputs only (BASELINE configs[3]'s per-GPU work; sharding.ShardedLandmarkDecoder): the sub-model of the listed vertices,
-    // 23 column tiles instead of 252 with the batch cut into chunks across workgroups (pipe_chunking) -- same kernel, same bits as
-    // the landmark rows of a full-output launch -- unless the caller pinned a kernel (A/B timing, diagnostics).
-    if (h->lmk_sub && !verts3d && !proj && !posed && (lmk_xy || lmk_px) &&
-        (h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice()) == DAD3D_KERNEL_AUTO && !(flags & DAD3D_COMPAT_CROSS_B3) && !h->d_trace) {
+    // 23 column tiles instead of 252 with the batch cut into chunks across workgroups (pipe_chunking / split_chunking) -- same kernel, same
+    // bits as the landmark rows of a full-output launch of the handle, default or split form -- unless the caller pinned the two-role or the
+    // pipelined kernel (A/B timing, diagnostics: the whole mesh then).
+    const int pinned = h->kernel_choice >= 0 ? h->kernel_choice : decode_kernel_choice();
+    const bool pinned_split = pinned == DAD3D_KERNEL_SPLIT_BF16 || pinned == DAD3D_KERNEL_SPLIT_F16;
+    if (h->lmk_sub && !verts3d && !proj && !posed && (lmk_xy || lmk_px) && !(flags & DAD3D_COMPAT_CROSS_B3) && !h->d_trace &&
+        (pinned == DAD3D_KERNEL_AUTO || (pinned_split && h->lmk_sub->c->d_bpack_pipe && h->lmk_sub->d_vtab))) {
+        // a handle on a split form keeps ITS arithmetic: the sub-model runs the same form (its phases dealt over workgroups: split_chunking)
+        // on the PARENT's scratch -- one stream per handle, and a landmark-only launch captured behind a full-output warm-up must not allocate
+        h->lmk_sub->kernel_choice = pinned_split ? pinned : (h->lmk_sub->c->d_bpack_pipe ? DAD3D_KERNEL_AUTO : DAD3D_KERNEL_TWO_ROLE);
+        if (pinned_split) {
+            dad3d_status sst = ensure_split_scratch(h, (batch + kSplitRows - 1) / kSplitRows, s);
+            if (sst) return sst;
+            h->lmk_sub->d_split_a = h->d_split_a, h->lmk_sub->split_cap = h->split_cap;
+        }
         dad3d_status st = decode_impl(h->lmk_sub, params, batch, flags, nullptr, nullptr, lmk_xy, lmk_px, nullptr, stream);
+        if (pinned_split) h->lmk_sub->d_split_a = nullptr, h->lmk_sub->split_cap = 0;  // (lent, not owned)
         if (!st && h->profiling) ++h->prof_launches;
         return st;
     }
@@ -668,20 +698,8 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         // fp32 MFMA chain in both forms: profiles/r06_split_error.md). Two launches.
         DAD3D_REQUIRE(!h->d_trace, "dad3d_flame_decode: the split kernels have no trace stamps");
         const int n_phase = (batch + kSplitRows - 1) / kSplitRows;
-        if (n_phase > h->split_cap) {
-            hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-            if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
-            DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone,
-                          "the first split-kernel decode of a handle (and the first at a larger batch) allocates: run it once before capturing a graph");
-            DAD3D_HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(h->d_split_a);
-            h->d_split_a = nullptr, h->split_cap = 0;
-            DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitBlockBytes));
-            // (the padding is copied into LDS, never read.) On the LAUNCH's stream: hipMemset is ordered on the null stream only, and a
-            // non-blocking stream's pre-pass overtook it -- zero planes under the first launch of a fork (found by the two-streams test)
-            DAD3D_HIP_TRY(hipMemsetAsync(h->d_split_a, 0, (size_t)n_phase * kSplitBlockBytes, s));
-            h->split_cap = n_phase;
-        }
+        dad3d_status sst = ensure_split_scratch(h, n_phase, s);
+        if (sst) return sst;
         SplitArgs sa{};
         sa.params = params;
         sa.bpack = h->c->d_bpack_pipe;
@@ -697,6 +715,7 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         sa.batch = batch;
         sa.n_phase = n_phase;
         sa.n_tiles = h->c->n_tiles_pipe;
+        split_chunking(sa.n_tiles, n_phase, &sa.n_chunks, &sa.phases_per_chunk);
         sa.n_verts = h->n_verts;
         sa.n_lmk = (lmk_xy || lmk_px) ? h->n_lmk : 0;
         sa.image_size = h->image_size;

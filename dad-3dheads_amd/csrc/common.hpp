@@ -180,9 +180,18 @@ struct SplitArgs {
                              // per-image constants D 9 | G 9 | s tx ty | pad of the phase
     float b_scale;           // DAD3D_KERNEL_SPLIT_F16: the power of two the basis is multiplied by in front of its fp16 split (split_basis_scale)
     int n_params, batch, n_phase, n_tiles, n_verts, n_lmk;
+    int n_chunks, phases_per_chunk;  // split_chunking: (1, n_phase) for the whole mesh
     float image_size;
     unsigned flags;
 };
+// A model of few tiles (the landmark sub-model: 23) cuts the launch's phases into chunks, one workgroup per (tile, chunk), up to 256 workgroups
+inline void split_chunking(int n_tiles, int n_phase, int* n_chunks, int* phases_per_chunk) {
+    *n_chunks = 1, *phases_per_chunk = n_phase;
+    const int max_chunks = 256 / n_tiles;
+    if (max_chunks < 2 || n_phase < 2) return;
+    *phases_per_chunk = (n_phase + max_chunks - 1) / max_chunks;
+    *n_chunks = (n_phase + *phases_per_chunk - 1) / *phases_per_chunk;
+}
 dad3d_status launch_flame_decode_split(const SplitArgs& a, int form, hipStream_t s);  // form: DAD3D_KERNEL_SPLIT_BF16 | DAD3D_KERNEL_SPLIT_F16
 float split_basis_scale(float max_abs);
 size_t flame_decode_split_lds_bytes();

@@ -226,17 +226,22 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the roles branch and loop on SGPRs, not under exec masks
-    // Block b runs on XCD b % 8 (observed, for speed only): an XCD gets a CONTIGUOUS run of tiles, so that the partial cache lines at the
-    // seams of neighbouring tiles' stores (runs of 240 / 160 bytes at 4-byte alignment) meet in ONE L2 when the stores are write-back (WB)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nt = a.n_tiles, big = nt & 7, per = nt >> 3;  // the first `big` XCDs hold per + 1 tiles
-    const int tile = xcd < big ? xcd * (per + 1) + slot : big * (per + 1) + (xcd - big) * per + slot;
-    const int v0 = tile * TV;
-    const int NP = a.n_phase, B = a.batch;
+    // Block b runs on XCD b % 8 (observed, for speed only): an XCD gets a CONTIGUOUS run of work items, so that the partial cache lines at the
+    // seams of neighbouring tiles' stores (runs of 240 / 160 bytes at 4-byte alignment) meet in ONE L2 when the stores are write-back (WB).
+    // A work item is (tile, chunk of the batch): one chunk for the whole mesh (252 tiles fill the chip); a model of few tiles -- the landmark
+    // sub-model, 23 -- has its phases dealt over up to 256 / n_tiles workgroups per tile (split_chunking), neighbours in the run, one L2.
+    const int n_work = a.n_tiles * a.n_chunks;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, big = n_work & 7, per = n_work >> 3;  // the first `big` XCDs hold per + 1 items
+    const int work = xcd < big ? xcd * (per + 1) + slot : big * (per + 1) + (xcd - big) * per + slot;
+    const int tile = work / a.n_chunks, chunk = work - tile * a.n_chunks, v0 = tile * TV;
+    const int pb = chunk * a.phases_per_chunk;               // this workgroup's phases: [pb, pb + NP) of the launch
+    const int NP = min(a.phases_per_chunk, a.n_phase - pb), B = a.batch;
+    if (NP <= 0) return;  // (uniform; cannot happen with split_chunking's counts)
 
     if (wave == 4) {
         // ====================================================== stager wave ===========================================================
         auto stage = [&](int p) {  // PLN / 1 KB + 2 requests of 1 KB (40 + 2 | 27 + 2)
-            const char* src = a.aplanes + (size_t)p * BLK + 16 * lane;
+            const char* src = a.aplanes + (size_t)(pb + p) * BLK + 16 * lane;
             char* dst = abuf + (p % 3) * PLN;
 #if defined(DAD3D_SPLIT_NO_GLDS)  // diagnostics: the same copy through registers -- a SLOW stager, the deterministic repro of section 4 of the log
 #pragma unroll 1
@@ -344,9 +349,9 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
                                   t.e0[1] + t.e1[1], t.e0[2] + t.e1[2], g.vt.x, g.vt.y);
     };
     auto store_call = [&](int q, const Geo& g, const VertexOut& o) {
-        const int b = q * QB + g.i;
+        const int b = (pb + q) * QB + g.i;
         const bool live = b < B && g.vlive && !((DAD3D_SPLIT_ABLATE & 256) && o.ox != 12345.678f);
-        const unsigned row0 = (unsigned)(q * QB) * (unsigned)a.n_verts;  // (scalar)
+        const unsigned row0 = (unsigned)((pb + q) * QB) * (unsigned)a.n_verts;  // (scalar)
         vertex_store_at<TO2D, WB ? 0 : DAD3D_PIPE_STORE_AUX>(cx, rs3, rsp, o, __float_as_int(g.vt.z), __float_as_int(g.vt.w), live && a.verts3d != nullptr, live && a.proj != nullptr,
                               live && nl > 0 && __float_as_int(g.vt.z) >= 0, g.off3 + row0 * 12u, g.offp + row0 * kPB, (unsigned)b * nl);
     };
@@ -389,14 +394,17 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
     }
 
     // ==================================================== mma waves ================================================================
-    // wave w = (kh = w >> 1, ch = w & 1) multiplies HALF of K against HALF of the tile's columns: bf16 groups [6 kh, 6 kh + 6) x the two
-    // 16-column blocks 2 ch, 2 ch + 1, plus the tail group 12 (k = 384..415) for ONE column block -- its block c0 = 2 ch + kh; the other
-    // is c1 = 2 ch + 1 - kh. The two K halves meet in the finishers: partial tile kh.
+    // wave w = (kh = w >> 1, ch = w & 1) multiplies HALF of K against HALF of the tile's columns: groups [6 kh, 6 kh + 6) x the two 16-column
+    // blocks 2 ch, 2 ch + 1; the tail group 12 (k = 384..415) belongs to the SECOND half: the kh = 1 waves multiply it for both of their
+    // blocks (84 | 42 MFMAs per phase against 72 | 36 -- the matrix pipe is not the phase's bound), so that a column's two partial sums are
+    // chain(groups 0..5) and chain(groups 6..12) wherever the column sits in its tile: the landmark sub-model (other tiles, other positions)
+    // returns the whole-mesh launch's bits. (The tail dealt by column block -- balanced counts -- made the order depend on the position.)
+    // The two K halves meet in the finishers: partial tile kh. c0 / c1: the wave's blocks in the order it parks them.
     // The pack holds, for MFMA group G of 16 k and column block c, lane (q = lane >> 4, n = lane & 15) the float4 k = 16 G + 4 q + 0..3
     // of column n: groups 2 g and 2 g + 1 are the lane's eight k of bf16 group g.
     const int kh = wave >> 1, ch = wave & 1, c0 = 2 * ch + kh, c1 = 2 * ch + 1 - kh, gbase = 6 * kh;
     const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + (size_t)tile * kPipeKGroups * 256 + lane;
-    float4 raw[6][2][2], rawt[2];  // [slot][column block c0 / c1][k half of the bf16 group]
+    float4 raw[6][2][2], rawt[2][2];  // [slot][column block c0 / c1][k half of the bf16 group]; the tail group's: kh = 1 only
 #pragma unroll
     for (int sl = 0; sl < 6; ++sl)  // ALL of it in flight, in the order the GEMM wants it (flame_decode_pipe.hip)
 #pragma unroll
@@ -407,8 +415,10 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) rawt[h] = bsrc[(size_t)((24 + h) * 4 + c0) * 64];
-    vec8 bp[6][2][NPL], bt[NPL];  // the wave's basis slice as NPL planes, resident for the launch
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rawt[cb][h] = kh ? bsrc[(size_t)((24 + h) * 4 + (cb ? c1 : c0)) * 64] : float4{0.f, 0.f, 0.f, 0.f};
+    vec8 bp[6][2][NPL], bt[2][NPL];  // the wave's basis slice as NPL planes, resident for the launch
     const char* afrag0 = abuf + (lane & 15) * RS + (lane >> 4) * 16;
     float* const ot0 = otile + kh * (QB * OS) + ((lane >> 4) * 4) * OS + (lane & 15);
     const float b_scale = S::kScaled ? a.b_scale : 1.0f;  // F16x2: the basis x a power of two (exact), so that no residual underflows
@@ -446,20 +456,6 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
             hi0 = S::mfma(x[0], b0[0], hi0), hi1 = S::mfma(x[0], b1[0], hi1);
         }
     };
-    auto products1 = [&](const vec8 (&x)[NPL], const vec8 (&b0)[NPL], f32x4& lo0, f32x4& hi0) {
-        if constexpr (NPL == 3) {
-            lo0 = S::mfma(x[0], b0[2], lo0);
-            hi0 = S::mfma(x[0], b0[0], hi0);
-            lo0 = S::mfma(x[2], b0[0], lo0);
-            lo0 = S::mfma(x[1], b0[1], lo0);
-            lo0 = S::mfma(x[0], b0[1], lo0);
-            lo0 = S::mfma(x[1], b0[0], lo0);
-        } else {
-            lo0 = S::mfma(x[0], b0[1], lo0);
-            hi0 = S::mfma(x[0], b0[0], hi0);
-            lo0 = S::mfma(x[1], b0[0], lo0);
-        }
-    };
 
     // one phase: per column block, hi += a1 b1 and lo += the five smaller products (measured as accurate as three accumulators by order
     // of magnitude, tools/split_probe.hip); FIRST: the basis slice is still arriving and is split slot by slot in front of its first use
@@ -470,7 +466,7 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
 #pragma unroll
         for (int sl = 0; sl < 6; ++sl) {
             if (FIRST) planes(raw[sl][0][0], raw[sl][0][1], bp[sl][0]), planes(raw[sl][1][0], raw[sl][1][1], bp[sl][1]);
-            read_frags(p, sl < 5 ? gbase + sl + 1 : 12, an);  // the tail group last
+            if (sl < 5 || kh) read_frags(p, sl < 5 ? gbase + sl + 1 : 12, an);  // the tail group last (second K half only)
             __builtin_amdgcn_sched_barrier(0);
             if ((DAD3D_SPLIT_ABLATE & 4) && !FIRST) {
 #pragma unroll
@@ -485,9 +481,9 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
         // every fragment of A(p) is in registers (the tail group's in `af`): the image may be overwritten, A(p + 1) has landed
         phase_barrier();  // B(p)
         if (!(DAD3D_SPLIT_ABLATE & 16) && p + 1 < NP) read_frags(p + 1, gbase, an);
-        if (FIRST) planes(rawt[0], rawt[1], bt);
+        if (FIRST && kh) planes(rawt[0][0], rawt[0][1], bt[0]), planes(rawt[1][0], rawt[1][1], bt[1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (!((DAD3D_SPLIT_ABLATE & 4) && !FIRST)) products1(af, bt, lo0, hi0);  // the tail group, column block c0 only
+        if (kh && !((DAD3D_SPLIT_ABLATE & 4) && !FIRST)) products2(af, bt[0], bt[1], lo0, hi0, lo1, hi1);  // the tail group
         __builtin_amdgcn_sched_barrier(0);
         // accumulators -> partial tile kh [image][column], small + large; D layout: row = (lane >> 4) * 4 + reg, column = lane & 15
         float* ot = ot0 + (p & 1) * (2 * QB * OS);
@@ -549,7 +545,7 @@ dad3d_status launch_split(const SplitArgs& a, hipStream_t s, PerDeviceOnce& attr
     }
     hipLaunchKernelGGL(split_params_kernel<S>, dim3(a.n_phase * kSplitRows), dim3(256), 0, s, a);
     const bool to2d = (a.flags & DAD3D_TO_2D) || !a.proj, wb = a.batch >= S::kWriteBackFrom;
-    const dim3 grid(a.n_tiles), block(64 * (5 + S::kFinishers));
+    const dim3 grid(a.n_tiles * a.n_chunks), block(64 * (5 + S::kFinishers));
     if (to2d && wb) hipLaunchKernelGGL((flame_decode_split_kernel<S, true, true>), grid, block, lds, s, a);
     else if (to2d) hipLaunchKernelGGL((flame_decode_split_kernel<S, true, false>), grid, block, lds, s, a);
     else if (wb) hipLaunchKernelGGL((flame_decode_split_kernel<S, false, true>), grid, block, lds, s, a);

@@ -282,3 +282,47 @@ def test_write_back_and_write_through_launches_return_the_same_bits(meshes):
     torch.cuda.synchronize()
     for k in ("verts3d", "proj", "lmk_xy", "lmk_px"):
         assert torch.equal(big[k][:100], small[k]), k
+
+
+@pytest.mark.parametrize("batch", [1, 16, 17, 100, 256, 700, 2048])
+def test_landmark_only_launches_of_a_split_handle_run_the_sub_model_and_return_the_full_launch_bits(meshes, batch):
+    """A handle on a split form keeps its arithmetic: landmark outputs only -> the sub-model of the listed vertices on the SAME form
+    (23 tiles, the launch's phases dealt over up to 11 workgroups per tile: split_chunking in csrc/common.hpp), bit for bit the landmark
+    rows of the whole-mesh launch -- duplicates in the list, a custom list, the write-back included or not."""
+    split, _ = meshes
+    rng = np.random.default_rng(batch)
+    for lm in (None, np.concatenate([rng.integers(0, 5023, 90), [7, 7, 5022, 0]]).astype(np.int64)):
+        if lm is not None:
+            split.set_landmarks(lm)
+        params = synthetic.synthetic_params(batch, seed=6800 + batch)
+        keep = torch.from_numpy(params.copy()).cuda()
+        only = split.decode(keep, verts3d=False, proj=False, landmarks=True, landmarks_px=True, mutate=(batch % 2 == 0))
+        full = split.decode(torch.from_numpy(params.copy()).cuda(), to_2d=True, landmarks=True, landmarks_px=True)
+        torch.cuda.synchronize()
+        assert torch.equal(only["lmk_xy"], full["lmk_xy"]) and torch.equal(only["lmk_px"], full["lmk_px"]), (batch, lm is None)
+        after = keep.cpu().numpy()
+        want = params.copy()
+        if batch % 2 == 0:
+            want[:, 411] = 0.0
+        assert np.array_equal(after, want)
+    assert _lib.load().dad3d_flame_num_landmark_vertices(split.flame._handle) > 0
+    split.set_landmarks(landmarks.canonical("445", synthetic.load_static()))
+
+
+def test_landmark_only_launch_of_a_split_handle_replays_from_a_graph_behind_a_full_warm_up(meshes):
+    """The sub-model borrows the parent's scratch: a landmark-only launch captured behind a full-output warm-up of the same batch size allocates
+    nothing (the first split launch at a batch size does, and refuses inside a capture)."""
+    split, _ = meshes
+    p = torch.from_numpy(synthetic.synthetic_params(300, seed=6900)).cuda()
+    want = split.decode(p.clone(), to_2d=True, landmarks=True, landmarks_px=True)  # warm-up: scratch of 19 phases
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    static_in = p.clone()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            out = split.decode(static_in, verts3d=False, proj=False, landmarks=True, landmarks_px=True)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["lmk_xy"], want["lmk_xy"]) and torch.equal(out["lmk_px"], want["lmk_px"])
