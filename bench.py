@@ -587,7 +587,7 @@ def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, s
     dad3d_flame_select_kernel(DAD3D_KERNEL_SPLIT_BF16): three bf16 planes, six products per K = 32; DAD3D_KERNEL_SPLIT_F16: two fp16
     planes, three products): a pre-pass + the tile kernel per step, both inside the timed launches; outputs held to the same goldens and
     bars as the fp32 leg. Not the default, not the headline: `value` / `dtype` / `roofline` stay on fp32."""
-    from dad_3dheads_amd import _lib
+    from dad_3dheads_amd import _lib, synthetic
 
     b = params.shape[0]
     twin = hm.fork()
@@ -629,6 +629,23 @@ def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, s
         out["outputs_verified"] = bool(dv < 5e-6 and dp < 1e-3 and gather_exact and out["verification"]["tz_zeroed_like_reference"])
     else:
         out["outputs_verified"] = None
+    # landmark outputs only on the same handle: the sub-model on the SAME form (phases dealt over workgroups), bit-equal to its whole-mesh launch
+    try:
+        lmk_only = torch.zeros_like(lmk_px)
+        call_l = (twin.flame._handle, p2.data_ptr(), b, _lib.MUTATE_PARAMS, None, None, None, lmk_only.data_ptr(), stream.cuda_stream)
+        tl, _ = events_per_step(lambda: lib.dad3d_flame_decode(*call_l), steps, stream, dev, warmup=20, settle=2)
+        b2 = 2048
+        params2 = torch.from_numpy(synthetic.synthetic_params(b2, seed=B256_SEED + 1)).to(dev)
+        lmk2 = torch.zeros((b2, N_LMK, 2), dtype=torch.int32, device=dev)
+        call_2 = (twin.flame._handle, params2.data_ptr(), b2, _lib.MUTATE_PARAMS, None, None, None, lmk2.data_ptr(), stream.cuda_stream)
+        t2, _ = events_per_step(lambda: lib.dad3d_flame_decode(*call_2), max(steps // 4, 20), stream, dev, warmup=10, settle=2)
+        same = bool(torch.equal(lmk_only, lmk_px))
+        out["landmarks_only"] = {"ms_per_step": tl * 1e3, "b2048_ms_per_step": t2 * 1e3, "b2048_images_per_sec": b2 / t2,
+                                 "bit_equal_to_this_handles_whole_mesh_launch": same, "b2048_nonzero": bool(int(lmk2.abs().max()) > 0)}
+        if out["outputs_verified"] is not None:
+            out["outputs_verified"] = bool(out["outputs_verified"] and same)
+    except Exception as e:
+        out["landmarks_only"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

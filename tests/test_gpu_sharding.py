@@ -308,6 +308,9 @@ def test_driver_command_carries_the_secondary_legs():
     assert sf.get("outputs_verified") is True, sf
     assert sf["verification"]["max_abs_3d"] < 5e-6 and sf["verification"]["max_abs_px"] < 1e-3 and sf["verification"]["landmark_gather_exact"]
     assert sf["ms_per_step"] < 0.030, sf  # measured 0.020-0.021 (the bf16 form 0.025, the fp32 leg 0.038)
+    for leg in (sp, sf):  # landmark outputs only on a split handle: its sub-model, its arithmetic
+        lo2 = leg["landmarks_only"]
+        assert "error" not in lo2 and lo2["bit_equal_to_this_handles_whole_mesh_launch"] is True and lo2["b2048_nonzero"] is True, lo2
     e2e = d["secondary"]["e2e_b64"]  # the north star's sentence, reported separately from the metric
     assert "error" not in e2e, e2e
     assert e2e["gpu_outputs_finite"] is True and e2e["cpu_reference_predictor"]["threads"] == 8 and e2e["ratio"] > 0 and e2e["north_star_target_ratio"] == 200
