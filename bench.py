@@ -629,6 +629,23 @@ def secondary_decode_b256_split(hm, lib, dev, params, golden, lmk_idx, stream, s
         out["outputs_verified"] = bool(dv < 5e-6 and dp < 1e-3 and gather_exact and out["verification"]["tz_zeroed_like_reference"])
     else:
         out["outputs_verified"] = None
+    # the contract's own step (configs[1]: 64 rows, 2-D projection + 3-D + int landmarks) on this form, against the default kernel's outputs
+    try:
+        b64 = BATCH
+        p64 = torch.from_numpy(synthetic.synthetic_params(b64, seed=GOLDEN_SEED)).to(dev)
+        bufs = {k: (torch.empty((b64, N_VERTS, 3), device=dev), torch.empty((b64, N_VERTS, 2), device=dev),
+                    torch.empty((b64, N_LMK, 2), dtype=torch.int32, device=dev)) for k in ("split", "default")}
+        calls = {k: (hnd, p64.data_ptr(), b64, _lib.TO_2D | _lib.MUTATE_PARAMS, bufs[k][0].data_ptr(), bufs[k][1].data_ptr(), None, bufs[k][2].data_ptr(),
+                     stream.cuda_stream) for k, hnd in (("split", twin.flame._handle), ("default", hm.flame._handle))}
+        # (4000 launches per pass: a pass shorter than ~30 ms measures the clock ramp behind the host-side verification above, not the kernel)
+        t64, _ = events_per_step(lambda: lib.dad3d_flame_decode(*calls["split"]), 4000, stream, dev, warmup=200, settle=settle)
+        _lib.check(lib.dad3d_flame_decode(*calls["default"]))
+        torch.cuda.synchronize(dev)
+        out["contract_step_b64"] = {"ms_per_step": t64 * 1e3, "images_per_sec": b64 / t64,
+                                    "max_abs_3d_vs_default_kernel": float((bufs["split"][0] - bufs["default"][0]).abs().max()),
+                                    "max_abs_px_vs_default_kernel": float((bufs["split"][1] - bufs["default"][1]).abs().max())}
+    except Exception as e:
+        out["contract_step_b64"] = {"error": f"{type(e).__name__}: {e}"}
     # landmark outputs only on the same handle: the sub-model on the SAME form (phases dealt over workgroups), bit-equal to its whole-mesh launch
     try:
         lmk_only = torch.zeros_like(lmk_px)

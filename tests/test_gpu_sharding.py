@@ -308,6 +308,9 @@ def test_driver_command_carries_the_secondary_legs():
     assert sf.get("outputs_verified") is True, sf
     assert sf["verification"]["max_abs_3d"] < 5e-6 and sf["verification"]["max_abs_px"] < 1e-3 and sf["verification"]["landmark_gather_exact"]
     assert sf["ms_per_step"] < 0.030, sf  # measured 0.020-0.021 (the bf16 form 0.025, the fp32 leg 0.038)
+    for leg in (sp, sf):  # the contract's own step on the split forms: within the bars of each other and the default kernel
+        c64 = leg["contract_step_b64"]
+        assert "error" not in c64 and c64["max_abs_3d_vs_default_kernel"] < 1e-6 and c64["max_abs_px_vs_default_kernel"] < 5e-4, c64
     for leg in (sp, sf):  # landmark outputs only on a split handle: its sub-model, its arithmetic
         lo2 = leg["landmarks_only"]
         assert "error" not in lo2 and lo2["bit_equal_to_this_handles_whole_mesh_launch"] is True and lo2["b2048_nonzero"] is True, lo2

@@ -13,6 +13,7 @@ s = d["secondary"]
 print("b256", s["decode_b256"]["ms_per_step"], s["decode_b256"]["frac"], s["decode_b256"]["outputs_verified"])
 print("split", json.dumps(s["decode_b256_split"]))
 print("split_f16", json.dumps(s["decode_b256_split_f16"]))
+print("b64 on the split forms", s["decode_b256_split"]["contract_step_b64"], s["decode_b256_split_f16"]["contract_step_b64"])
 print("lmk", json.dumps(s["decode_b256"]["landmarks_only"]))
 print("e2e", json.dumps(s["e2e_b64"]))
 print("verified", s["outputs_verified"], "render", s["render_b64"]["us_per_batch"])
