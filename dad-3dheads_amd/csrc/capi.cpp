@@ -79,8 +79,9 @@ struct dad3d_flame {
     bool profiling = false;
     unsigned long long* d_trace = nullptr;  // diagnostics (dad3d_flame_debug_trace)
     uint64_t trace_capacity = 0;
-    char* d_split_a = nullptr;    // scratch of the bf16x3 split kernel (flame_decode_split.hip): params rows as bf16 planes + per-image
+    char* d_split_a = nullptr;    // scratch of the split kernels (flame_decode_split.hip): params rows as planes + per-image
     int split_cap = 0;            // constants; split_cap phases of 16 images
+    std::vector<char*> split_retired;  // smaller scratches it outgrew: kept until destroy -- a graph captured at a smaller batch still points there
     hipEvent_t ev_first = nullptr, ev_last = nullptr;  // bracket a run of back-to-back launches
     int prof_launches = 0;
     // Landmark-only launches (SURVEY 7.1 "landmark-only fast path"; BASELINE configs[3]'s per-GPU work): a second handle over the
@@ -390,6 +391,7 @@ void dad3d_flame_destroy(dad3d_flame* h) {
     for (void* p : {(void*)h->d_lmk_head, (void*)h->d_lmk_next, (void*)h->d_sync, (void*)h->d_imgc, (void*)h->d_bwd_partials,
                     (void*)h->d_grad_partials, (void*)h->d_vtab, (void*)h->d_split_a})
         if (p) (void)hipFree(p);
+    for (char* p : h->split_retired) (void)hipFree(p);
     if (h->ev_first) (void)hipEventDestroy(h->ev_first);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     delete h;
@@ -413,6 +415,7 @@ dad3d_status dad3d_flame_fork(dad3d_flame* parent, dad3d_flame** out) {
     h->arrive_total = 0;
     h->cap_nbb = 0;
     h->d_split_a = nullptr, h->split_cap = 0;
+    h->split_retired.clear();
     h->profiling = false;
     h->d_trace = nullptr;
     h->ev_first = h->ev_last = nullptr;
@@ -567,6 +570,7 @@ static dad3d_status build_landmark_subset(dad3d_flame* h, const int64_t* idx, in
     q->d_bwd_partials = q->d_grad_partials = nullptr;
     q->bwd_cap = 0, q->grad_cap = 0, q->arrive_total = 0, q->cap_nbb = 0;
     q->d_split_a = nullptr, q->split_cap = 0;
+    q->split_retired.clear();
     q->profiling = false;
     q->d_trace = nullptr, q->trace_capacity = 0;
     q->ev_first = q->ev_last = nullptr;
@@ -624,8 +628,7 @@ static dad3d_status ensure_split_scratch(dad3d_flame* h, int n_phase, hipStream_
     if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
     DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone,
                   "the first split-kernel decode of a handle (and the first at a larger batch) allocates: run it once before capturing a graph");
-    DAD3D_HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(h->d_split_a);
+    if (h->d_split_a) h->split_retired.push_back(h->d_split_a);  // (2.6 KB per image: never worth a dangling pointer in somebody's graph)
     h->d_split_a = nullptr, h->split_cap = 0;
     DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_split_a), (size_t)n_phase * kSplitBlockBytes));
     // (the padding is copied into LDS, never read.) On the LAUNCH's stream: hipMemset is ordered on the null stream only, and a

@@ -240,6 +240,15 @@ def test_split_kernel_refuses_what_it_does_not_cover_and_replays_from_a_graph(me
     torch.cuda.synchronize()
     for k in ("verts3d", "proj", "lmk_xy"):
         assert torch.equal(out[k], want[k])
+    # the scratch grows with a larger batch; the graph captured at 48 rows keeps the one it was captured with
+    big = split.decode(torch.from_numpy(synthetic.synthetic_params(400, seed=6501)).cuda(), to_2d=True, landmarks=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(big["verts3d"]).all())
+    out["verts3d"].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ("verts3d", "proj", "lmk_xy"):
+        assert torch.equal(out[k], want[k])
     # a fork shares the basis and owns its scratch
     twin = split.fork()
     twin.flame.select_kernel(split.split_form)

@@ -15,15 +15,21 @@ from collections import defaultdict
 
 
 def short(name):
-    if "flame_decode_split_kernel" in name or "split_params_kernel" in name:  # templates over the split form (Bf16x3 | F16x2)
+    if "flame_decode_split_kernel" in name or "split_params_kernel" in name:  # templates over the split form (Bf16x3 | F16x2), TO2D, WB
         form = "F16x2" if "F16x2" in name else "Bf16x3"
-        return ("split_params_kernel" if "split_params" in name else "flame_decode_split_kernel") + f"<{form}>"
+        if "split_params" in name:
+            return f"split_params_kernel<{form}>"
+        flags = name[name.index(form) + len(form):].split(">")[0]  # ", false, false"
+        return f"flame_decode_split_kernel<{form}{flags}>"
     for key in ("flame_decode_pipe_kernel<true, false>", "flame_decode_pipe_kernel<false, false>", "flame_decode_pipe_kernel<true, true>",
                 "flame_decode_kernel", "raster_kernel<0>", "raster_blend_kernel",
                 "tri_geometry_kernel<true, 2>", "tri_geometry_kernel<true, 0>", "readjust_kernel", "ncclDevKernel", "copyBuffer", "fillBuffer"):
         if key in name:
             return key
     return name.split("(")[0][-60:]
+
+
+PAIRS = defaultdict(list)
 
 
 def main():
@@ -36,9 +42,15 @@ def main():
         leg = bench["secondary"]["decode_b256"]
         n_b256 = 50 + (int(leg["settle_passes"]) + 1) * int(leg["steps"])
     dur, seen_false = defaultdict(list), 0
+    last_pre = {}
     for r in sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Start_Timestamp"])):  # launch order
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         k = short(r["Kernel_Name"])
+        if k.startswith("split_params_kernel"):
+            last_pre[k[len("split_params_kernel"):]] = d  # "<Form>"
+        elif k.startswith("flame_decode_split_kernel"):
+            form = k[len("flame_decode_split_kernel"):].split(",")[0] + ">"
+            PAIRS[k].append((last_pre.get(form, 0.0), d))  # a step = the pre-pass in front of it + the tile kernel
         if k == "flame_decode_pipe_kernel<false, false>":
             seen_false += 1
             first_leg = (seen_false <= n_b256) if n_b256 is not None else d > 25.0
@@ -69,14 +81,15 @@ def main():
 
 def split_lines(dur, bench):
     for form, legname, what in (("Bf16x3", "decode_b256_split", "bf16x3 split"), ("F16x2", "decode_b256_split_f16", "fp16x2 split")):
-        sp = dur.get(f"flame_decode_split_kernel<{form}>", [])
-        pre = dur.get(f"split_params_kernel<{form}>", [])
-        if sp and bench and legname in bench.get("secondary", {}):
+        pairs = PAIRS.get(f"flame_decode_split_kernel<{form}, false, false>", [])  # the leg's 3-component launches (its sub-legs are 2-D / landmark-only)
+        if pairs and bench and legname in bench.get("secondary", {}):
             leg = bench["secondary"][legname]
             steps = int(leg["steps"])
-            a, b = sum(sp[-steps:]) / steps, sum(pre[-steps:]) / max(len(pre[-steps:]), 1)
-            print(f"{what}, B = 256: tile kernel {a:.3f} us + pre-pass {b:.3f} us = {a + b:.3f} us per step over the timed pass (the last {steps} launches); "
-                  f"the same run printed secondary.{legname}.ms_per_step {leg['ms_per_step'] * 1e3:.3f} us (the difference is the gap between the two launches)")
+            timed = pairs[-steps:]
+            a, b = sum(t for _, t in timed) / len(timed), sum(p for p, _ in timed) / len(timed)
+            print(f"{what}, B = 256: tile kernel {a:.3f} us + pre-pass {b:.3f} us = {a + b:.3f} us per step over the timed pass (the last {len(timed)} of the leg's "
+                  f"{len(pairs)} 3-component launches); the same run printed secondary.{legname}.ms_per_step {leg['ms_per_step'] * 1e3:.3f} us (the difference is the "
+                  f"gap between the two launches)")
     lm = dur.get("flame_decode_pipe_kernel<true, true>", [])
     if lm:
         print(f"landmark sub-model (chunked grid): {len(lm)} launches, B = 256 and B = 2048 legs together; min {min(lm):.2f} us, max {max(lm):.2f} us")
