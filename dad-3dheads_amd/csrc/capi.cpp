@@ -43,12 +43,14 @@ struct FlameConsts {
     float *d_bpack = nullptr, *d_jdirs = nullptr, *d_j0 = nullptr, *d_w8 = nullptr;
     float* d_bpack_pipe = nullptr;  // basis of the 20-vertex tiles + jaw-joint columns (flame_decode_pipe.hip); null: model not covered
     float split_b_scale = 1.0f;     // DAD3D_KERNEL_SPLIT_F16: the power of two its entries are multiplied by in front of their fp16 split
+    float* d_bpack_f16 = nullptr;   // ... and the pack split into its two fp16 planes, built by the first decode in that form (ensure_basis_f16)
+    std::mutex f16_mu;
     int n_tiles_pipe = 0;
     float* d_gpack = nullptr;  // basis^T in MFMA fragment order for dad3d_flame_grad_inputs: built by the first training forward
     std::mutex gpack_mutex;
     ~FlameConsts() {
         DeviceGuard guard(device);
-        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8, (void*)d_gpack, (void*)d_bpack_pipe})
+        for (void* p : {(void*)d_bpack, (void*)d_jdirs, (void*)d_j0, (void*)d_w8, (void*)d_gpack, (void*)d_bpack_pipe, (void*)d_bpack_f16})
             if (p) (void)hipFree(p);
     }
 };
@@ -621,6 +623,32 @@ static uint64_t trace_entries_two_role(const dad3d_flame* h, int batch) {
 }
 static uint64_t trace_entries_pipe(const dad3d_flame* h) { return (uint64_t)h->c->n_tiles_pipe * 8 * 32; }
 
+// DAD3D_KERNEL_SPLIT_F16: the model's basis pack as two fp16 planes, built on the device by the first decode in that form (26.7 MB for the whole
+// mesh: not spent on models that never use the form), shared by forks. The builder waits for its kernel before publishing the pointer: a fork
+// on another stream must not read a pack still being written.
+static dad3d_status ensure_basis_f16(dad3d_flame* h, hipStream_t s) {
+    FlameConsts* c = h->c.get();
+    std::lock_guard<std::mutex> lock(c->f16_mu);
+    if (c->d_bpack_f16) return DAD3D_OK;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (s != nullptr) (void)hipStreamIsCapturing(s, &capture);
+    DAD3D_REQUIRE(capture == hipStreamCaptureStatusNone, "the first fp16-split decode of a model builds its basis planes: run it once before capturing a graph");
+    const size_t bytes = (size_t)c->n_tiles_pipe * kPipeKGroups * 4 * 64 * 4 * sizeof(float);
+    float* d = nullptr;
+    DAD3D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    dad3d_status st = launch_split_basis_f16(c->d_bpack_pipe, d, c->n_tiles_pipe, c->split_b_scale, s);
+    if (st == DAD3D_OK && hipStreamSynchronize(s) != hipSuccess) {
+        set_error("ensure_basis_f16: hipStreamSynchronize failed");
+        st = DAD3D_E_HIP;
+    }
+    if (st) {
+        (void)hipFree(d);
+        return st;
+    }
+    c->d_bpack_f16 = d;
+    return DAD3D_OK;
+}
+
 // Scratch of the split kernels (pre-pass -> tile kernel): n_phase blocks of kSplitBlockBytes, grown on demand -- never inside a capture.
 static dad3d_status ensure_split_scratch(dad3d_flame* h, int n_phase, hipStream_t s) {
     if (n_phase <= h->split_cap) return DAD3D_OK;
@@ -702,10 +730,14 @@ static dad3d_status decode_impl(dad3d_flame* h, float* params, int batch, unsign
         DAD3D_REQUIRE(!h->d_trace, "dad3d_flame_decode: the split kernels have no trace stamps");
         const int n_phase = (batch + kSplitRows - 1) / kSplitRows;
         dad3d_status sst = ensure_split_scratch(h, n_phase, s);
+        if (!sst && choice == DAD3D_KERNEL_SPLIT_F16) sst = ensure_basis_f16(h, s);
+        // (and the landmark sub-model's, so that a landmark-only launch captured behind a full-output warm-up builds nothing)
+        if (!sst && choice == DAD3D_KERNEL_SPLIT_F16 && h->lmk_sub && h->lmk_sub->c->d_bpack_pipe) sst = ensure_basis_f16(h->lmk_sub, s);
         if (sst) return sst;
         SplitArgs sa{};
         sa.params = params;
         sa.bpack = h->c->d_bpack_pipe;
+        sa.bpack_f16 = h->c->d_bpack_f16;
         sa.vtab = h->d_vtab;
         sa.lmk_next = h->d_lmk_next;
         sa.verts3d = verts3d;

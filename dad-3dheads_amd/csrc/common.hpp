@@ -170,6 +170,7 @@ constexpr int kSplitBlockBytes = kSplitPlaneBytes + kSplitConstBytes;           
 struct SplitArgs {
     float* params;           // [B,P] (tz written when DAD3D_MUTATE_PARAMS)
     const float* bpack;      // the pipelined kernel's pack (PipeArgs::bpack)
+    const float* bpack_f16;  // DAD3D_KERNEL_SPLIT_F16: the same pack split into its two fp16 planes (launch_split_basis_f16), same size and addressing
     const float4* vtab;      // [V] as PipeArgs::vtab
     const int* lmk_next;     // [n_lmk]
     float* verts3d;          // [B,V,3] or null
@@ -194,6 +195,7 @@ inline void split_chunking(int n_tiles, int n_phase, int* n_chunks, int* phases_
 }
 dad3d_status launch_flame_decode_split(const SplitArgs& a, int form, hipStream_t s);  // form: DAD3D_KERNEL_SPLIT_BF16 | DAD3D_KERNEL_SPLIT_F16
 float split_basis_scale(float max_abs);
+dad3d_status launch_split_basis_f16(const float* bpack, float* bpack_f16, int n_tiles, float scale, hipStream_t s);
 size_t flame_decode_split_lds_bytes();
 
 // Backward of the per-vertex half of the decode (flame_backward.hip). Per-image constants, natural joint order:

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
     // The pack holds, for MFMA group G of 16 k and column block c, lane (q = lane >> 4, n = lane & 15) the float4 k = 16 G + 4 q + 0..3
     // of column n: groups 2 g and 2 g + 1 are the lane's eight k of bf16 group g.
     const int kh = wave >> 1, ch = wave & 1, c0 = 2 * ch + kh, c1 = 2 * ch + 1 - kh, gbase = 6 * kh;
-    const float4* bsrc = reinterpret_cast<const float4*>(a.bpack) + (size_t)tile * kPipeKGroups * 256 + lane;
+    // F16x2 reads the pack ALREADY split (split_basis_f16_kernel, once per model): the two float4 of a 16-bit group hold plane 0 and plane 1
+    // of the lane's eight k -- same bytes, same addresses, no conversion in the first phase and no second copy of the slice in registers
+    const float4* bsrc = reinterpret_cast<const float4*>(S::kScaled ? a.bpack_f16 : a.bpack) + (size_t)tile * kPipeKGroups * 256 + lane;
     float4 raw[6][2][2], rawt[2][2];  // [slot][column block c0 / c1][k half of the bf16 group]; the tail group's: kh = 1 only
 #pragma unroll
     for (int sl = 0; sl < 6; ++sl)  // ALL of it in flight, in the order the GEMM wants it (flame_decode_pipe.hip)
@@ -421,18 +423,16 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
     vec8 bp[6][2][NPL], bt[2][NPL];  // the wave's basis slice as NPL planes, resident for the launch
     const char* afrag0 = abuf + (lane & 15) * RS + (lane >> 4) * 16;
     float* const ot0 = otile + kh * (QB * OS) + ((lane >> 4) * 4) * OS + (lane & 15);
-    const float b_scale = S::kScaled ? a.b_scale : 1.0f;  // F16x2: the basis x a power of two (exact), so that no residual underflows
     const float out_scale = S::kScaled ? 1.0f / (S::kScaleA * a.b_scale) : 1.0f;
     auto planes = [&](const float4& lo, const float4& hi, vec8 (&out)[NPL]) {
-        float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (S::kScaled) {  // element by element, opaque to the vectoriser: a vector multiply becomes v_pk_mul_f32, which this file keeps out
-#pragma unroll           // (section 4 of the log)
-            for (int i = 0; i < 8; ++i) asm("v_mul_f32 %0, %1, %2" : "=v"(e[i]) : "v"(e[i]), "v"(b_scale));
-        }
-        f32x8 r = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]};
+        if constexpr (S::kScaled) {
+            out[0] = __builtin_bit_cast(vec8, lo), out[NPL - 1] = __builtin_bit_cast(vec8, hi);
+        } else {
+            f32x8 r = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int pl = 0; pl + 1 < NPL; ++pl) r = peel(r, out[pl]);
-        out[NPL - 1] = __builtin_convertvector(r, vec8);
+            for (int pl = 0; pl + 1 < NPL; ++pl) r = peel(r, out[pl]);
+            out[NPL - 1] = __builtin_convertvector(r, vec8);
+        }
     };
     auto read_frags = [&](int p, int g, vec8 (&dst)[NPL]) {
         const char* ab = afrag0 + (p % 3) * PLN + 64 * g;
@@ -526,6 +526,34 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
         if ((n & 255u) == 255u) printf("CLK n_phase %d cycles %lld ticks %lld MHz %.0f cycles/phase %.0f\n", NP, dc, dw, (double)dc / (dw * 10.0) * 1e3, (double)dc / NP);
     }
 #endif
+}
+
+// ---- F16x2: the basis pack split once per model: (x S) -> h1 | h2, the two float4 of every 16-bit group replaced by its two planes -------
+__global__ __launch_bounds__(256) void split_basis_f16_kernel(const float4* src, float4* dst, int n_tiles, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // (tile, 16-bit group g, entry r = column block x lane)
+    const size_t n = (size_t)n_tiles * kSplitKGroups * 256;
+    if (i >= n) return;
+    const size_t t = i / (kSplitKGroups * 256), g = (i / 256) % kSplitKGroups, r = i % 256;
+    const size_t i0 = (t * kPipeKGroups + 2 * g) * 256 + r, i1 = i0 + 256;
+    const float4 lo = src[i0], hi = src[i1];
+    float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    f16x8 h1, h2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = e[k] * scale;  // a power of two: exact
+        h1[k] = (_Float16)x;
+        h2[k] = (_Float16)(x - (float)h1[k]);
+    }
+    dst[i0] = __builtin_bit_cast(float4, h1), dst[i1] = __builtin_bit_cast(float4, h2);
+}
+
+dad3d_status launch_split_basis_f16(const float* bpack, float* bpack_f16, int n_tiles, float scale, hipStream_t s) {
+    static_assert(kPipeKGroups == 2 * kSplitKGroups, "two MFMA groups of 16 k per 16-bit group of 32");
+    const size_t n = (size_t)n_tiles * kSplitKGroups * 256;
+    hipLaunchKernelGGL(split_basis_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(bpack),
+                       reinterpret_cast<float4*>(bpack_f16), n_tiles, scale);
+    DAD3D_HIP_TRY(hipGetLastError());
+    return DAD3D_OK;
 }
 
 size_t flame_decode_split_lds_bytes() { return (size_t)Lds<Bf16x3>::total; }
