@@ -208,7 +208,9 @@ DAD3D_EXPORT dad3d_status dad3d_flame_handoff_timeouts(dad3d_flame* h, unsigned*
  * planes (22 significant bits; params rows x 16 and the basis x a power of two chosen at dad3d_flame_create so that no residual
  * underflows -- exact scalings) and three products: half the matrix instructions, about 1.4x the speed of the bf16 form at large
  * batches, error against float64 between the bf16 form's and the fp32 chain's (same file); a params entry beyond +-4094 makes ITS
- * row inf/NaN in this form only. A handle on a split form runs its landmark-only launches on the sub-model in the SAME form (bit-identical
+ * row inf/NaN in this form only. The first decode of a model in this form also builds the
+ * basis as two fp16 planes on the device (26.7 MB for the whole mesh, shared by forks; not inside a graph capture). A handle on a split form runs its
+ * landmark-only launches on the sub-model in the SAME form (bit-identical
  * to its whole-mesh launches). The environment variable DAD3D_DECODE_KERNEL=v1|force_pipe|split|split_f16 sets the
  * process-wide default for handles that have not chosen (A/B timing; anything else = automatic). */
 #define DAD3D_KERNEL_AUTO 0
