@@ -506,9 +506,17 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
     const long long clk0 = clock64(), wall0 = wall_clock64();
 #endif
     read_frags(0, gbase, af);
-    phase(0, std::true_type{});
+    if constexpr (S::kScaled) {  // the planes arrive split: name them (register moves at most) and run ONE copy of the phase's code
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl) planes(raw[sl][0][0], raw[sl][0][1], bp[sl][0]), planes(raw[sl][1][0], raw[sl][1][1], bp[sl][1]);
+        planes(rawt[0][0], rawt[0][1], bt[0]), planes(rawt[1][0], rawt[1][1], bt[1]);
 #pragma unroll 1
-    for (int p = 1; p < NP; ++p) phase(p, std::false_type{});
+        for (int p = 0; p < NP; ++p) phase(p, std::false_type{});
+    } else {
+        phase(0, std::true_type{});
+#pragma unroll 1
+        for (int p = 1; p < NP; ++p) phase(p, std::false_type{});
+    }
     // the drain: this wave's share of the last two tiles (the basis registers are dead). Tile NP - 2 has been visible since B(NP - 1)
     if (S::kFinishers == 3 && wave < 2 && !(DAD3D_SPLIT_ABLATE & 1)) {
         const Geo g = make_geo(3 + wave);
