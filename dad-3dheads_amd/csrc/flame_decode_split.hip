@@ -451,9 +451,11 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
             lo0 = S::mfma(x[1], b0[0], lo0), lo1 = S::mfma(x[1], b1[0], lo1);
             hi0 = S::mfma(x[0], b0[0], hi0), hi1 = S::mfma(x[0], b1[0], hi1);
         } else {
-            lo0 = S::mfma(x[0], b0[1], lo0), lo1 = S::mfma(x[0], b1[1], lo1);
-            lo0 = S::mfma(x[1], b0[0], lo0), lo1 = S::mfma(x[1], b1[0], lo1);
-            hi0 = S::mfma(x[0], b0[0], hi0), hi1 = S::mfma(x[0], b1[0], hi1);
+            // consecutive instructions share an operand register (b0[0], x[0] | b1[0], x[0]): 1-3 % of a launch against the order that alternates
+            // the column blocks -- these kernels pay for switching (log section 8); no accumulator is touched twice in a row, and BOTH blocks
+            // add their small products in the same order (h2 g1, then h1 g2): a column's bits must not depend on which block it sits in
+            lo0 = S::mfma(x[1], b0[0], lo0), hi0 = S::mfma(x[0], b0[0], hi0), lo0 = S::mfma(x[0], b0[1], lo0);
+            lo1 = S::mfma(x[1], b1[0], lo1), hi1 = S::mfma(x[0], b1[0], hi1), lo1 = S::mfma(x[0], b1[1], lo1);
         }
     };
 
