@@ -444,12 +444,14 @@ __global__ __launch_bounds__(64 * (5 + S::kFinishers), (5 + S::kFinishers + 3) /
     // F16x2: hi += h1 g1, lo += h1 g2 + h2 g1 -- two column blocks interleaved: no MFMA waits for the one in front of it
     auto products2 = [&](const vec8 (&x)[NPL], const vec8 (&b0)[NPL], const vec8 (&b1)[NPL], f32x4& lo0, f32x4& hi0, f32x4& lo1, f32x4& hi1) {
         if constexpr (NPL == 3) {
-            lo0 = S::mfma(x[0], b0[2], lo0), lo1 = S::mfma(x[0], b1[2], lo1);
-            lo0 = S::mfma(x[2], b0[0], lo0), lo1 = S::mfma(x[2], b1[0], lo1);
+            // neighbours share an operand register (b0 | b0 | b0, then x1 | x1, x0 | x0 | x0 | x0 across the two blocks): 1-2 % at 1024+ images against
+            // alternating the blocks product by product (these kernels pay for switching, log section 8); no accumulator twice in a row; both
+            // blocks add their small products in ONE order (a3 b1, a2 b1, a2 b2, a1 b2, a1 b3): a column's bits do not depend on its block
+            lo0 = S::mfma(x[2], b0[0], lo0), hi0 = S::mfma(x[0], b0[0], hi0), lo0 = S::mfma(x[1], b0[0], lo0);
+            lo1 = S::mfma(x[2], b1[0], lo1), hi1 = S::mfma(x[0], b1[0], hi1), lo1 = S::mfma(x[1], b1[0], lo1);
             lo0 = S::mfma(x[1], b0[1], lo0), lo1 = S::mfma(x[1], b1[1], lo1);
             lo0 = S::mfma(x[0], b0[1], lo0), lo1 = S::mfma(x[0], b1[1], lo1);
-            lo0 = S::mfma(x[1], b0[0], lo0), lo1 = S::mfma(x[1], b1[0], lo1);
-            hi0 = S::mfma(x[0], b0[0], hi0), hi1 = S::mfma(x[0], b1[0], hi1);
+            lo0 = S::mfma(x[0], b0[2], lo0), lo1 = S::mfma(x[0], b1[2], lo1);
         } else {
             // consecutive instructions share an operand register (b0[0], x[0] | b1[0], x[0]): 1-3 % of a launch against the order that alternates
             // the column blocks -- these kernels pay for switching (log section 8); no accumulator is touched twice in a row, and BOTH blocks
