@@ -88,3 +88,18 @@ def test_rccl_binding_resolves_its_entry_points():
     for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString"):
         assert hasattr(lib, name), name
     assert ctypes.sizeof(rccl._UniqueId) == 128
+
+
+def test_python_constants_mirror_the_header():
+    """The flag / kernel-choice / dtype numbers `_lib.py` passes through ctypes are the header's `#define`s (a new constant on one side only
+    would select another kernel without an error)."""
+    text = open(os.path.join(ROOT, "include", "dad3d.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+DAD3D_([A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)u?\b", text)}
+    checked = 0
+    for name, value in vars(_lib).items():
+        if name.isupper() and isinstance(value, int) and name in defines:
+            assert defines[name] == value, (name, defines[name], value)
+            checked += 1
+    assert checked >= 10, checked
+    for must in ("KERNEL_AUTO", "KERNEL_TWO_ROLE", "KERNEL_PIPELINED", "KERNEL_SPLIT_BF16", "KERNEL_SPLIT_F16", "TO_2D", "MUTATE_PARAMS", "FLIP_Z"):
+        assert must in defines and getattr(_lib, must) == defines[must], must
