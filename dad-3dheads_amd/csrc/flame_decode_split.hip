@@ -203,9 +203,10 @@ __global__ __launch_bounds__(256) void split_params_kernel(SplitArgs a) {
 
 // Barrier protocol (every wave executes n_phase + 2 phase barriers: S0, B(0) .. B(n_phase - 1), E). Window p = between B(p - 1) and B(p).
 //   S0      A(0) and its constants are in LDS (and the tile's rows of the vertex table)
-//   B(p)    mma waves: every fragment of A(p) has been READ (its last six MFMAs and the parking of tile p follow the barrier);
+//   B(p)    mma waves: every fragment of A(p) has been READ (the tail group's MFMAs -- second K half -- and the parking of tile p follow it);
 //           stager: A(p + 1) and its constants have LANDED (A(p + 2) is in flight); finishers: tile p - 2 has been consumed
-//   E       tile n_phase - 1 is parked (in the window in front of it and behind it -- the drain -- mma waves 0 and 1 finish too)
+//   E       tile n_phase - 1 is parked (in the window in front of it and behind it -- the drain -- mma waves 0 and 1 finish too: Bf16x3)
+// Phases are the WORKGROUP's: [pb, pb + NP) of the launch when a model of few tiles has its phases dealt over chunks (split_chunking).
 // mma waves, window p + 1: first fragments of A(p + 1) requested, tail MFMAs of phase p, tile p parked in tile pair p & 1, slots 0..5 of
 // phase p + 1. Stager, window p: requests the planes of phase p + 2 into image (p + 2) % 3 -- last read in front of B(p - 1) -- and its
 // constants into ring slot (p + 2) & 7, then waits for phase p + 1's (requested a window earlier: a global -> LDS round trip is as
